@@ -1,0 +1,230 @@
+"""ctypes binding of the CPU oracle (oracle/libvo_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under openvo_amd/ may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libvo_oracle.so")
+_SRC = ["src/sgbm.c", "src/imgproc.c", "src/orb.c", "src/match.c", "src/geom.c", "vo_oracle.h"]
+
+
+def build_oracle(force=False):
+    newest = max(os.path.getmtime(os.path.join(_HERE, s)) for s in _SRC)
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < newest:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libvo_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+class SgbmParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("minDisparity", "numDisparities", "blockSize", "P1", "P2", "disp12MaxDiff",
+                 "preFilterCap", "uniquenessRatio", "speckleWindowSize", "speckleRange", "mode")]
+
+
+def sgbm_params(d, mode=0):
+    return SgbmParams(*[int(d[k]) for k in
+                        ("minDisparity", "numDisparities", "blockSize", "P1", "P2", "disp12MaxDiff",
+                         "preFilterCap", "uniquenessRatio", "speckleWindowSize", "speckleRange")],
+                      int(d.get("mode", mode)))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        _lib = ctypes.CDLL(_LIB)
+        _lib.vo_ref_ratio_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.vo_ref_rigid_clique.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_double, ctypes.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def bgr2gray(bgr):
+    bgr = _c(bgr, np.uint8)
+    h, w = bgr.shape[:2]
+    out = np.empty((h, w), np.uint8)
+    lib().vo_ref_bgr2gray(_p(bgr), w, h, _p(out))
+    return out
+
+
+def remap_bilinear(src, map1, map2):
+    src, map1, map2 = _c(src, np.uint8), _c(map1, np.int16), _c(map2, np.uint16)
+    h, w = map2.shape
+    out = np.empty((h, w), np.uint8)
+    lib().vo_ref_remap_bilinear(_p(src), src.shape[1], src.shape[0], _p(map1), _p(map2), w, h, _p(out))
+    return out
+
+
+def sgbm_compute(left, right, params, mode=0, stages=False):
+    left, right = _c(left, np.uint8), _c(right, np.uint8)
+    h, w = left.shape
+    p = sgbm_params(params, mode)
+    raw = np.empty((h, w), np.int16)
+    med = np.empty((h, w), np.int16)
+    fin = np.empty((h, w), np.int16)
+    rc = lib().vo_ref_sgbm_compute(_p(left), _p(right), w, h, ctypes.byref(p), _p(raw), _p(med), _p(fin))
+    if rc != 0:
+        raise ValueError("oracle sgbm: bad parameters")
+    return (raw, med, fin) if stages else fin
+
+
+def sgbm_cost_volume(left, right, params):
+    left, right = _c(left, np.uint8), _c(right, np.uint8)
+    h, w = left.shape
+    p = sgbm_params(params)
+    D = p.numDisparities
+    minx1 = max(p.minDisparity + D, 0)
+    maxx1 = w + min(p.minDisparity, 0)
+    C = np.empty((h, maxx1 - minx1, D), np.int16)
+    lib().vo_ref_sgbm_cost_volume(_p(left), _p(right), w, h, ctypes.byref(p), _p(C))
+    return C
+
+
+def median3x3_s16(img):
+    img = _c(img, np.int16)
+    out = np.empty_like(img)
+    lib().vo_ref_median3x3_s16(_p(img), img.shape[1], img.shape[0], _p(out))
+    return out
+
+
+def filter_speckles(img, new_val, max_size, max_diff):
+    out = _c(img, np.int16).copy()
+    lib().vo_ref_filter_speckles(_p(out), out.shape[1], out.shape[0], int(new_val), int(max_size), int(max_diff))
+    return out
+
+
+def orb_detect_and_compute(img, mask, nfeatures=500, blur_mode=0, cap=None):
+    """Returns dict(xy, size, angle, response, octave, desc); img/mask may be strided views."""
+    img = _c(img, np.uint8)
+    h, w = img.shape
+    if mask is not None:
+        mask = _c(mask, np.uint8)
+    cap = cap or (2 * nfeatures + 4096)
+    xy = np.empty((cap, 2), np.float32)
+    size = np.empty(cap, np.float32)
+    angle = np.empty(cap, np.float32)
+    resp = np.empty(cap, np.float32)
+    octv = np.empty(cap, np.int32)
+    desc = np.empty((cap, 32), np.uint8)
+    n = ctypes.c_int(0)
+    lib().vo_ref_orb_detect_and_compute(_p(img), w, h, w, _p(mask) if mask is not None else None, w,
+                                        int(nfeatures), int(blur_mode), _p(xy), _p(size), _p(angle),
+                                        _p(resp), _p(octv), _p(desc), cap, ctypes.byref(n))
+    n = n.value
+    return dict(xy=xy[:n].copy(), size=size[:n].copy(), angle=angle[:n].copy(),
+                response=resp[:n].copy(), octave=octv[:n].copy(), desc=desc[:n].copy())
+
+
+def fast_score_map(img, threshold=20):
+    img = _c(img, np.uint8)
+    out = np.empty_like(img)
+    lib().vo_ref_fast_score_map(_p(img), img.shape[1], img.shape[0], img.shape[1], int(threshold), _p(out))
+    return out
+
+
+def orb_level_size(w, h, level):
+    lw, lh = ctypes.c_int(), ctypes.c_int()
+    lib().vo_ref_orb_level_size(w, h, level, ctypes.byref(lw), ctypes.byref(lh))
+    return lw.value, lh.value
+
+
+def resize_linear_exact(src, dw, dh):
+    src = _c(src, np.uint8)
+    out = np.empty((dh, dw), np.uint8)
+    lib().vo_ref_resize_linear_exact(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(out), dw, dh, dw)
+    return out
+
+
+def bf_knn2_hamming(q, t):
+    q, t = _c(q, np.uint8), _c(t, np.uint8)
+    idx = np.empty((len(q), 2), np.int32)
+    dist = np.empty((len(q), 2), np.int32)
+    lib().vo_ref_bf_knn2_hamming(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+    return idx, dist
+
+
+def ratio_filter(idx, dist, ratio):
+    idx, dist = _c(idx, np.int32), _c(dist, np.int32)
+    qo = np.empty(len(idx), np.int32)
+    to = np.empty(len(idx), np.int32)
+    m = lib().vo_ref_ratio_filter(_p(idx), _p(dist), len(idx), float(ratio), _p(qo), _p(to))
+    if m < 0:
+        raise IndexError("list index out of range")
+    return qo[:m].copy(), to[:m].copy()
+
+
+def reproject_to_3d(disp, Q):
+    disp, Q = _c(disp, np.float32), _c(Q, np.float64)
+    out = np.empty(disp.shape + (3,), np.float32)
+    lib().vo_ref_reproject_to_3d(_p(disp), disp.shape[1], disp.shape[0], _p(Q), _p(out))
+    return out
+
+
+def points3d_at(disp16, Q, roi, xy):
+    disp16, Q, xy = _c(disp16, np.int16), _c(Q, np.float64), _c(xy, np.float32).reshape(-1, 2)
+    h, w = disp16.shape
+    out = np.empty((len(xy), 3), np.float32)
+    st = np.empty(len(xy), np.uint8)
+    lib().vo_ref_points3d_at(_p(disp16), w, h, _p(Q), int(roi[0]), int(roi[1]), int(roi[2]), int(roi[3]),
+                             _p(xy), len(xy), _p(out), _p(st))
+    return out, st
+
+
+def bilinear_at(img3d, xy):
+    img3d, xy = _c(img3d, np.float32), _c(xy, np.float32).reshape(-1, 2)
+    h, w = img3d.shape[:2]
+    out = np.empty((len(xy), 3), np.float32)
+    st = np.empty(len(xy), np.uint8)
+    lib().vo_ref_bilinear_at(_p(img3d), w, h, _p(xy), len(xy), _p(out), _p(st))
+    return out, st
+
+
+def umeyama(src, dst, force_rotation=True):
+    src, dst = _c(src, np.float32), _c(dst, np.float32)
+    T = np.empty((3, 4), np.float64)
+    s = ctypes.c_double(0)
+    rc = lib().vo_ref_umeyama(_p(src), _p(dst), len(src), int(force_rotation), _p(T), ctypes.byref(s))
+    if rc == -1:
+        raise ValueError("Umeyama algorithm needs at least 3 points for affine transformation estimation.")
+    if rc == -2:
+        raise ValueError("Points cannot be colinear")
+    return T, s.value
+
+
+def rodrigues(R):
+    R = _c(R, np.float64)
+    r = np.empty(3, np.float64)
+    lib().vo_ref_rodrigues(_p(R), _p(r))
+    return r.reshape(3, 1)
+
+
+def rigid_clique(prev, cur, thr):
+    prev, cur = _c(prev, np.float32), _c(cur, np.float32)
+    mask = np.zeros(len(cur), np.int64)
+    lib().vo_ref_rigid_clique(_p(prev), _p(cur), len(cur), float(thr), _p(mask))
+    return mask
+
+
+def svd3(A):
+    A = _c(A, np.float64)
+    U, w, Vt = np.empty((3, 3)), np.empty(3), np.empty((3, 3))
+    lib().vo_ref_svd3(_p(A), _p(U), _p(w), _p(Vt))
+    return U, w, Vt
