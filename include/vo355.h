@@ -1,0 +1,150 @@
+/*
+ * vo355.h -- C ABI of libvo355.so: the MI355X (gfx950) implementation of openVO's
+ * stereo-odometry hot path.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * The reference (KevinSpevak/openVO) has no FFI of its own: its boundary is the set of
+ * cv2 object call sites inside StereoCamera.compute_3d and StereoOdometer.update.  Each
+ * entry point below names the reference line(s) it replaces (paths relative to
+ * /root/reference/src/openVO/).  The Python classes in openvo_amd/ bind these with ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success, a negative VO_E_* code otherwise;
+ * vo_last_error(ctx) returns a message owned by the context.  Host pointers are
+ * caller-owned, C-contiguous, and never retained past the call.  Device memory belongs to
+ * the opaque context.  A context is bound to one device and one HIP stream and is NOT
+ * thread-safe; use one context per thread / per GPU.  No C++ exception crosses the ABI.
+ * There is no CPU fallback: if no gfx950 device is usable, vo_create fails.
+ */
+#ifndef VO355_H
+#define VO355_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vo_ctx vo_ctx;
+
+enum {
+    VO_OK = 0,
+    VO_E_ARG = -1,     /* bad argument / shape */
+    VO_E_HIP = -2,     /* HIP runtime error (message has the hipError string) */
+    VO_E_STATE = -3,   /* call order violated (e.g. no disparity in that slot yet) */
+    VO_E_CAP = -4,     /* capacity given at vo_create exceeded */
+    VO_E_NUMERIC = -5  /* degenerate input (Umeyama: <3 points / colinear) */
+};
+
+#define VO_NUM_SLOTS 4 /* frame slots per context: the odometer keeps prev, current, next */
+
+/* lifetime ------------------------------------------------------------------------- */
+int vo_create(int device_id, int max_w, int max_h, int max_disp, int max_kp, vo_ctx** out);
+void vo_destroy(vo_ctx* ctx);
+const char* vo_last_error(const vo_ctx* ctx);
+int vo_device_name(const vo_ctx* ctx, char* buf, int buflen);
+int vo_synchronize(vo_ctx* ctx);
+
+/* one-off configuration (stereo_camera.py:16-27) ------------------------------------ */
+/* map_left_1/2, map_right_1/2 of cv2.initUndistortRectifyMap(..., CV_16SC2)  [stereo_camera.py:19-22] */
+int vo_set_rectify_maps(vo_ctx* ctx, int cam /*0=L,1=R*/, const int16_t* map1 /*h*w*2*/,
+                        const uint16_t* map2 /*h*w*/, int w, int h);
+/* cv2.StereoSGBM_create positional parameters [stereo_camera.py:23-27]; mode 0 = MODE_SGBM
+ * (5 paths, the reference's default), 1 = MODE_HH (8 paths) */
+int vo_set_sgbm(vo_ctx* ctx, int minDisparity, int numDisparities, int blockSize, int P1, int P2,
+                int disp12MaxDiff, int preFilterCap, int uniquenessRatio, int speckleWindowSize,
+                int speckleRange, int mode);
+/* Q of cv2.stereoRectify [stereo_camera.py:17-18], row-major 4x4 */
+int vo_set_Q(vo_ctx* ctx, const double* Q16);
+/* slice bounds used by crop_to_valid_region_left [stereo_camera.py:35-37]:
+ * rows y0:y1, cols x0:x1 where (x0,y0,x1,y1) = valid_region_left (quirk kept) */
+int vo_set_roi(vo_ctx* ctx, int x0, int y0, int x1, int y1);
+
+/* per frame pair (stereo_camera.py:43-55) -------------------------------------------- */
+/* cvtColor(BGR2GRAY) if channels==3 [:44-47]; remap x2 unless preprocessed [:48-50].
+ * Leaves rectified gray left/right on the device in `slot`. */
+int vo_upload_pair(vo_ctx* ctx, int slot, const uint8_t* left, const uint8_t* right, int w, int h,
+                   int channels, int preprocessed);
+/* self.stereoSGBM.compute(L, R) [:51]: int16 disparity x16 of the slot's pair; kept on the
+ * device; disp16_out (h*w) may be NULL */
+int vo_sgbm_compute(vo_ctx* ctx, int slot, int16_t* disp16_out);
+/* stand-alone stereoSGBM.compute on host images (the cv2 object seam) */
+int vo_sgbm_compute_host(vo_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h,
+                         int16_t* disp16_out);
+/* lazy materialisation of compute_3d's return values [:51-55], FULL (uncropped) images */
+int vo_download_disparity_f32(vo_ctx* ctx, int slot, float* out /*h*w*/);
+int vo_download_xyz(vo_ctx* ctx, int slot, float* out /*h*w*3*/); /* cv2.reprojectImageTo3D [:52] */
+int vo_download_left(vo_ctx* ctx, int slot, uint8_t* out /*h*w*/);
+int vo_download_right(vo_ctx* ctx, int slot, uint8_t* out /*h*w*/);
+/* stand-alone helpers at the cv2 seams */
+int vo_cvt_bgr2gray(vo_ctx* ctx, const uint8_t* bgr, int w, int h, uint8_t* gray);      /* [:45,47] */
+int vo_remap(vo_ctx* ctx, int cam, const uint8_t* src, int w, int h, uint8_t* dst);     /* [:30,33] */
+int vo_reproject_to_3d(vo_ctx* ctx, const float* disp, int w, int h, const double* Q16,
+                       float* xyz /*h*w*3*/);                                           /* [:52] */
+
+/* features (stereo_odometer.py:22,38-41,117) ------------------------------------------ */
+/* orb.detectAndCompute(next_img, feature_mask(next_disp)) on the slot's cropped left image.
+ * mask_mode 0: no mask; 1: feature_mask fused -- pixel allowed iff
+ * min_disp16 <= disp16 <= max_disp16 (MIN/MAX_VALID_DISPARITY*16, [stereo_odometer.py:6-7,38-41]).
+ * Results stay on the device in the slot; host outputs may each be NULL.  Keypoints come in
+ * canonical order (octave, y, x).  *n_out may exceed nfeatures (OpenCV keeps response ties). */
+int vo_orb_detect_and_compute(vo_ctx* ctx, int slot, int nfeatures, int mask_mode, int min_disp16,
+                              int max_disp16, float* kp_xy /*cap*2*/, float* kp_size,
+                              float* kp_angle, float* kp_response, int32_t* kp_octave,
+                              uint8_t* desc /*cap*32*/, int cap, int* n_out);
+/* the cv2 object seam on host arrays: img (h rows, stride bytes), mask NULL or same geometry */
+int vo_orb_detect_and_compute_host(vo_ctx* ctx, const uint8_t* img, int w, int h, int stride,
+                                   const uint8_t* mask, int mask_stride, int nfeatures,
+                                   float* kp_xy, float* kp_size, float* kp_angle,
+                                   float* kp_response, int32_t* kp_octave, uint8_t* desc, int cap,
+                                   int* n_out);
+int vo_slot_num_keypoints(vo_ctx* ctx, int slot, int* n_out);
+
+/* matching (stereo_odometer.py:163-164) ------------------------------------------------ */
+/* matcher.knnMatch(q, t, k=2) with NORM_HAMMING: idx/dist nq*2, ascending distance, ties ->
+ * lower train index; -1 / INT32_MAX where the train set has fewer than 2 rows */
+int vo_bf_knn2_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                       int32_t* idx, int32_t* dist);
+/* m[0].distance < ratio * m[1].distance in double on float32 distances [:164]; host only */
+int vo_ratio_filter(const int32_t* idx, const int32_t* dist, int nq, double ratio, int32_t* q_out,
+                    int32_t* t_out, int* m_out);
+
+/* 3-D lookup (stereo_camera.py:52 fused with stereo_odometer.py:50-79) ------------------ */
+/* bilinear_interpolate_pixels of the slot's (cropped) reprojected image at float keypoint
+ * coords; status 0 ok, 1 NaN, 2 no usable tap (reference raises ZeroDivisionError) */
+int vo_points3d_at(vo_ctx* ctx, int slot, const float* xy, int n, float* xyz_out /*n*3*/,
+                   uint8_t* status_out);
+/* same on an explicit host H*W*3 float image (the reference method's own signature) */
+int vo_bilinear_at(vo_ctx* ctx, const float* img3d, int w, int h, const float* xy, int n,
+                   float* out, uint8_t* status_out);
+
+/* fused pair step: point_clouds(kps_a, kps_b, desc_a, desc_b, 3d_a, 3d_b) [:162-175] entirely on
+ * the device for two slots: kNN-2 + ratio + both 3-D lookups.  Returns M matches in match order
+ * (ascending query index); outputs may be NULL except m_out. */
+int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int32_t* q_idx,
+                    int32_t* t_idx, float* pts_a /*cap*3*/, float* pts_b, uint8_t* status_a,
+                    uint8_t* status_b, int cap, int* m_out);
+
+/* pose (stereo_odometer.py:82-105,177-223) ---------------------------------------------- */
+/* cv2.estimateAffine3D(src, dst, force_rotation) Umeyama [:190,204]: T 3x4 row-major, scale */
+int vo_umeyama(vo_ctx* ctx, const float* src /*m*3*/, const float* dst, int m, int force_rotation,
+               double* T12, double* scale_out);
+/* rigid_body_filter [:82-105] */
+int vo_rigid_clique(vo_ctx* ctx, const float* prev, const float* cur, int m, double thr,
+                    int64_t* mask_out /*m*/);
+/* cv2.Rodrigues(R)[0] [:212]; host only */
+int vo_rodrigues(const double* R9, double* r3);
+
+/* instrumentation ------------------------------------------------------------------------ */
+/* hipEvent timing of the kernels launched on the context stream.  Stage ids: */
+enum { VO_T_UPLOAD = 0, VO_T_SGBM_COST, VO_T_SGBM_AGG, VO_T_SGBM_WTA, VO_T_SGBM_POST, VO_T_ORB,
+       VO_T_MATCH, VO_T_POSE, VO_T_NSTAGES };
+int vo_enable_timing(vo_ctx* ctx, int on);
+/* accumulated milliseconds and launch counts per stage since the last reset */
+int vo_get_timings(vo_ctx* ctx, double* ms_out /*VO_T_NSTAGES*/, int64_t* launches_out, int reset);
+/* algorithmic cost-volume cells (width1*H*D) of the last vo_sgbm_compute, and number of
+ * aggregation-path launches it made */
+int vo_sgbm_last_geometry(vo_ctx* ctx, int64_t* cells, int* n_paths);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

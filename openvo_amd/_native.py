@@ -1,0 +1,343 @@
+"""ctypes binding of libvo355.so (C ABI: include/vo355.h).
+
+The library is built in-tree by `build_native()` (hipcc, gfx950).  There is no CPU fallback:
+creating a `Context` without a usable HIP device raises `VoError`.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvo355.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+VO_NUM_SLOTS = 4
+T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose")
+
+# every symbol include/vo355.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "vo_create", "vo_destroy", "vo_last_error", "vo_device_name", "vo_synchronize",
+    "vo_set_rectify_maps", "vo_set_sgbm", "vo_set_Q", "vo_set_roi", "vo_upload_pair",
+    "vo_sgbm_compute", "vo_sgbm_compute_host", "vo_download_disparity_f32", "vo_download_xyz",
+    "vo_download_left", "vo_download_right", "vo_cvt_bgr2gray", "vo_remap", "vo_reproject_to_3d",
+    "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints",
+    "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
+    "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
+    "vo_sgbm_last_geometry",
+]
+
+
+class VoError(RuntimeError):
+    """Raised for any non-zero status of the native library (code in .code)."""
+
+    def __init__(self, code, msg):
+        super().__init__("libvo355 error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build_native(force=False):
+    """Compile openvo_amd/csrc/*.hip for gfx950 into openvo_amd/libvo355.so."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "vo355.h"))
+    srcs.append(os.path.join(_HERE, "..", "include", "vo_orb_pattern.inc"))
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", _CSRC, "-j4"] + (["-B"] if force else []),
+                              stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libvo355.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libvo355.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.vo_last_error.restype = ctypes.c_char_p
+        L.vo_last_error.argtypes = [ctypes.c_void_p]
+        L.vo_destroy.restype = None
+        L.vo_destroy.argtypes = [ctypes.c_void_p]
+        vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+        L.vo_create.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(vp)]
+        L.vo_device_name.argtypes = [vp, ctypes.c_char_p, ci]
+        L.vo_synchronize.argtypes = [vp]
+        L.vo_set_rectify_maps.argtypes = [vp, ci, vp, vp, ci, ci]
+        L.vo_set_sgbm.argtypes = [vp] + [ci] * 11
+        L.vo_set_Q.argtypes = [vp, vp]
+        L.vo_set_roi.argtypes = [vp, ci, ci, ci, ci]
+        L.vo_upload_pair.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci]
+        L.vo_sgbm_compute.argtypes = [vp, ci, vp]
+        L.vo_sgbm_compute_host.argtypes = [vp, vp, vp, ci, ci, vp]
+        for f in (L.vo_download_disparity_f32, L.vo_download_xyz, L.vo_download_left, L.vo_download_right):
+            f.argtypes = [vp, ci, vp]
+        L.vo_cvt_bgr2gray.argtypes = [vp, vp, ci, ci, vp]
+        L.vo_remap.argtypes = [vp, ci, vp, ci, ci, vp]
+        L.vo_reproject_to_3d.argtypes = [vp, vp, ci, ci, vp, vp]
+        L.vo_orb_detect_and_compute.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]
+        L.vo_orb_detect_and_compute_host.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]
+        L.vo_slot_num_keypoints.argtypes = [vp, ci, vp]
+        L.vo_bf_knn2_hamming.argtypes = [vp, vp, ci, vp, ci, vp, vp]
+        L.vo_ratio_filter.argtypes = [vp, vp, ci, cd, vp, vp, vp]
+        L.vo_points3d_at.argtypes = [vp, ci, vp, ci, vp, vp]
+        L.vo_bilinear_at.argtypes = [vp, vp, ci, ci, vp, ci, vp, vp]
+        L.vo_point_clouds.argtypes = [vp, ci, ci, cd, vp, vp, vp, vp, vp, vp, ci, vp]
+        L.vo_umeyama.argtypes = [vp, vp, vp, ci, ci, vp, vp]
+        L.vo_rigid_clique.argtypes = [vp, vp, vp, ci, cd, vp]
+        L.vo_rodrigues.argtypes = [vp, vp]
+        L.vo_enable_timing.argtypes = [vp, ci]
+        L.vo_get_timings.argtypes = [vp, vp, vp, ci]
+        L.vo_sgbm_last_geometry.argtypes = [vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class Context:
+    """One device context (one HIP stream).  Not thread-safe: one per thread / per GPU."""
+
+    def __init__(self, device=0, max_w=1280, max_h=720, max_disp=128, max_kp=2000):
+        self._lib = lib()
+        h = ctypes.c_void_p()
+        rc = self._lib.vo_create(int(device), int(max_w), int(max_h), int(max_disp), int(max_kp), ctypes.byref(h))
+        if rc != 0:
+            raise VoError(rc, (self._lib.vo_last_error(None) or b"").decode())
+        self._h = h
+        self.device, self.max_w, self.max_h, self.max_disp, self.max_kp = device, max_w, max_h, max_disp, max_kp
+        self.kp_cap = max_kp * 2 + 1024
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise VoError(rc, (self._lib.vo_last_error(self._h) or b"").decode())
+
+    # ---- configuration
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._ck(self._lib.vo_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def synchronize(self):
+        self._ck(self._lib.vo_synchronize(self._h))
+
+    def set_rectify_maps(self, cam, map1, map2):
+        map1, map2 = _c(map1, np.int16), _c(map2, np.uint16)
+        h, w = map2.shape
+        self._ck(self._lib.vo_set_rectify_maps(self._h, cam, _p(map1), _p(map2), w, h))
+
+    def set_sgbm(self, p, mode=0):
+        self._ck(self._lib.vo_set_sgbm(self._h, *[int(p[k]) for k in (
+            "minDisparity", "numDisparities", "blockSize", "P1", "P2", "disp12MaxDiff", "preFilterCap",
+            "uniquenessRatio", "speckleWindowSize", "speckleRange")], int(p.get("mode", mode))))
+
+    def set_Q(self, Q):
+        Q = _c(Q, np.float64)
+        self._ck(self._lib.vo_set_Q(self._h, _p(Q)))
+
+    def set_roi(self, x0, y0, x1, y1):
+        self._ck(self._lib.vo_set_roi(self._h, int(x0), int(y0), int(x1), int(y1)))
+
+    # ---- per pair
+    def upload_pair(self, slot, left, right, preprocessed):
+        if left.shape != right.shape:
+            raise ValueError("left/right shapes differ")
+        ch = 3 if left.ndim == 3 else 1
+        left, right = _c(left, np.uint8), _c(right, np.uint8)
+        h, w = left.shape[:2]
+        self._ck(self._lib.vo_upload_pair(self._h, slot, _p(left), _p(right), w, h, ch, int(bool(preprocessed))))
+        return w, h
+
+    def sgbm_compute(self, slot, shape=None):
+        out = np.empty(shape, np.int16) if shape is not None else None
+        self._ck(self._lib.vo_sgbm_compute(self._h, slot, _p(out)))
+        return out
+
+    def sgbm_compute_host(self, left, right):
+        left, right = _c(left, np.uint8), _c(right, np.uint8)
+        h, w = left.shape
+        out = np.empty((h, w), np.int16)
+        self._ck(self._lib.vo_sgbm_compute_host(self._h, _p(left), _p(right), w, h, _p(out)))
+        return out
+
+    def download_disparity_f32(self, slot, shape):
+        out = np.empty(shape, np.float32)
+        self._ck(self._lib.vo_download_disparity_f32(self._h, slot, _p(out)))
+        return out
+
+    def download_xyz(self, slot, shape):
+        out = np.empty(tuple(shape) + (3,), np.float32)
+        self._ck(self._lib.vo_download_xyz(self._h, slot, _p(out)))
+        return out
+
+    def download_left(self, slot, shape, right=False):
+        out = np.empty(shape, np.uint8)
+        f = self._lib.vo_download_right if right else self._lib.vo_download_left
+        self._ck(f(self._h, slot, _p(out)))
+        return out
+
+    def cvt_bgr2gray(self, bgr):
+        bgr = _c(bgr, np.uint8)
+        h, w = bgr.shape[:2]
+        out = np.empty((h, w), np.uint8)
+        self._ck(self._lib.vo_cvt_bgr2gray(self._h, _p(bgr), w, h, _p(out)))
+        return out
+
+    def remap(self, cam, src, out_shape):
+        src = _c(src, np.uint8)
+        out = np.empty(out_shape, np.uint8)
+        self._ck(self._lib.vo_remap(self._h, cam, _p(src), src.shape[1], src.shape[0], _p(out)))
+        return out
+
+    def reproject_to_3d(self, disp, Q):
+        disp, Q = _c(disp, np.float32), _c(Q, np.float64)
+        out = np.empty(disp.shape + (3,), np.float32)
+        self._ck(self._lib.vo_reproject_to_3d(self._h, _p(disp), disp.shape[1], disp.shape[0], _p(Q), _p(out)))
+        return out
+
+    # ---- features
+    def _kp_buffers(self, cap):
+        return dict(xy=np.empty((cap, 2), np.float32), size=np.empty(cap, np.float32),
+                    angle=np.empty(cap, np.float32), response=np.empty(cap, np.float32),
+                    octave=np.empty(cap, np.int32), desc=np.empty((cap, 32), np.uint8))
+
+    @staticmethod
+    def _trim(b, n):
+        return {k: v[:n] for k, v in b.items()}
+
+    def orb_slot(self, slot, nfeatures, mask_mode, min_d16=0, max_d16=0):
+        cap = self.kp_cap
+        b = self._kp_buffers(cap)
+        n = ctypes.c_int(0)
+        self._ck(self._lib.vo_orb_detect_and_compute(self._h, slot, int(nfeatures), int(mask_mode), int(min_d16),
+                                                     int(max_d16), _p(b["xy"]), _p(b["size"]), _p(b["angle"]),
+                                                     _p(b["response"]), _p(b["octave"]), _p(b["desc"]), cap,
+                                                     ctypes.byref(n)))
+        return self._trim(b, n.value)
+
+    def orb_host(self, img, mask, nfeatures):
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise ValueError("ORB input must be a 2-D uint8 image")
+        if img.strides[1] != 1:
+            img = np.ascontiguousarray(img)
+        h, w = img.shape
+        mstride = 0
+        if mask is not None:
+            mask = np.asarray(mask, dtype=np.uint8)
+            if mask.shape != img.shape:
+                raise ValueError("mask shape differs from image shape")
+            if mask.strides[1] != 1:
+                mask = np.ascontiguousarray(mask)
+            mstride = mask.strides[0]
+        cap = self.kp_cap
+        b = self._kp_buffers(cap)
+        n = ctypes.c_int(0)
+        self._ck(self._lib.vo_orb_detect_and_compute_host(self._h, _p(img), w, h, img.strides[0], _p(mask), mstride,
+                                                          int(nfeatures), _p(b["xy"]), _p(b["size"]), _p(b["angle"]),
+                                                          _p(b["response"]), _p(b["octave"]), _p(b["desc"]), cap,
+                                                          ctypes.byref(n)))
+        return self._trim(b, n.value)
+
+    # ---- matching / 3-D / pose
+    def bf_knn2(self, q, t):
+        q, t = _c(q, np.uint8).reshape(-1, 32), _c(t, np.uint8).reshape(-1, 32)
+        idx = np.empty((len(q), 2), np.int32)
+        dist = np.empty((len(q), 2), np.int32)
+        self._ck(self._lib.vo_bf_knn2_hamming(self._h, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist)))
+        return idx, dist
+
+    def ratio_filter(self, idx, dist, ratio):
+        idx, dist = _c(idx, np.int32), _c(dist, np.int32)
+        qo, to = np.empty(len(idx), np.int32), np.empty(len(idx), np.int32)
+        m = ctypes.c_int(0)
+        rc = self._lib.vo_ratio_filter(_p(idx), _p(dist), len(idx), float(ratio), _p(qo), _p(to), ctypes.byref(m))
+        if rc != 0:
+            raise IndexError("list index out of range")  # what m[1] raises in the reference
+        return qo[:m.value], to[:m.value]
+
+    def points3d_at(self, slot, xy):
+        xy = _c(xy, np.float32).reshape(-1, 2)
+        out = np.empty((len(xy), 3), np.float32)
+        st = np.empty(len(xy), np.uint8)
+        self._ck(self._lib.vo_points3d_at(self._h, slot, _p(xy), len(xy), _p(out), _p(st)))
+        return out, st
+
+    def bilinear_at(self, img3d, xy):
+        img3d, xy = _c(img3d, np.float32), _c(xy, np.float32).reshape(-1, 2)
+        h, w = img3d.shape[:2]
+        out = np.empty((len(xy), 3), np.float32)
+        st = np.empty(len(xy), np.uint8)
+        self._ck(self._lib.vo_bilinear_at(self._h, _p(img3d), w, h, _p(xy), len(xy), _p(out), _p(st)))
+        return out, st
+
+    def point_clouds(self, slot_a, slot_b, ratio):
+        cap = self.kp_cap
+        q, t = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        pa, pb = np.empty((cap, 3), np.float32), np.empty((cap, 3), np.float32)
+        sa, sb = np.empty(cap, np.uint8), np.empty(cap, np.uint8)
+        m = ctypes.c_int(0)
+        self._ck(self._lib.vo_point_clouds(self._h, slot_a, slot_b, float(ratio), _p(q), _p(t), _p(pa), _p(pb),
+                                           _p(sa), _p(sb), cap, ctypes.byref(m)))
+        m = m.value
+        return q[:m], t[:m], pa[:m], pb[:m], sa[:m], sb[:m]
+
+    def umeyama(self, src, dst, force_rotation=True):
+        src, dst = _c(src, np.float32).reshape(-1, 3), _c(dst, np.float32).reshape(-1, 3)
+        if len(src) != len(dst):
+            raise ValueError("Point sets need to have the same size")
+        T = np.empty((3, 4), np.float64)
+        s = ctypes.c_double(0)
+        self._ck(self._lib.vo_umeyama(self._h, _p(src), _p(dst), len(src), int(bool(force_rotation)), _p(T),
+                                      ctypes.byref(s)))
+        return T, s.value
+
+    def rigid_clique(self, prev, cur, thr):
+        prev, cur = _c(prev, np.float32).reshape(-1, 3), _c(cur, np.float32).reshape(-1, 3)
+        mask = np.zeros(len(cur), np.int64)
+        self._ck(self._lib.vo_rigid_clique(self._h, _p(prev), _p(cur), len(cur), float(thr), _p(mask)))
+        return mask
+
+    @staticmethod
+    def rodrigues(R):
+        R = _c(R, np.float64)
+        r = np.empty(3, np.float64)
+        lib().vo_rodrigues(_p(R), _p(r))
+        return r.reshape(3, 1)
+
+    # ---- instrumentation
+    def enable_timing(self, on=True):
+        self._ck(self._lib.vo_enable_timing(self._h, int(on)))
+
+    def timings(self, reset=False):
+        ms = np.zeros(len(T_STAGES), np.float64)
+        n = np.zeros(len(T_STAGES), np.int64)
+        self._ck(self._lib.vo_get_timings(self._h, _p(ms), _p(n), int(reset)))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(T_STAGES)}
+
+    def sgbm_last_geometry(self):
+        cells, paths = ctypes.c_int64(0), ctypes.c_int(0)
+        self._ck(self._lib.vo_sgbm_last_geometry(self._h, ctypes.byref(cells), ctypes.byref(paths)))
+        return cells.value, paths.value

@@ -1,0 +1,651 @@
+// 3-D lookup and pose arithmetic on gfx950.
+//   cv2.reprojectImageTo3D                       [reference stereo_camera.py:52]
+//   bilinear_interpolate_pixels / point_clouds   [reference stereo_odometer.py:50-79,162-175]
+//   rigid_body_filter                            [reference stereo_odometer.py:82-105]
+//   cv2.estimateAffine3D(force_rotation=True)    [reference stereo_odometer.py:190,204]
+//   cv2.Rodrigues                                [reference stereo_odometer.py:212]
+// Floating point here follows the reference operation by operation (float32 / float64 as numpy
+// and OpenCV evaluate them); this file is compiled with -ffp-contract=off so no FMA is formed.
+#include <math.h>
+#include "vo_internal.h"
+
+struct QMat { double q[16]; };
+
+// one pixel of reprojectImageTo3D (OpenCV 4.x): homg = Q*[x y d 1] summed left to right in
+// double; out_i = (float)homg_i, then out_i = (float)((double)out_i * (1/homg_3))
+__device__ __forceinline__ void reproject_px(const QMat& Q, int x, int y, float d, float* out)
+{
+    const double v[4] = { (double)x, (double)y, (double)d, 1.0 };
+    double hg[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s = s + Q.q[i * 4 + k] * v[k];
+        hg[i] = s;
+    }
+    const double ialpha = 1.0 / hg[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float f = (float)hg[i];
+        out[i] = (float)((double)f * ialpha);
+    }
+}
+
+__global__ void k_reproject(const float* __restrict__ disp, int w, int h, QMat Q, float* __restrict__ xyz)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    float p[3];
+    reproject_px(Q, x, y, disp[(size_t)y * w + x], p);
+    float* o = xyz + ((size_t)y * w + x) * 3;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+}
+
+__global__ void k_reproject_disp16(const int16_t* __restrict__ disp16, int w, int h, QMat Q, float* __restrict__ xyz)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    float p[3];
+    reproject_px(Q, x, y, (float)disp16[(size_t)y * w + x] / 16.0f, p);
+    float* o = xyz + ((size_t)y * w + x) * 3;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+}
+
+// openVO's bilinear lookup; TAP supplies the float3 at cropped coords (x, y)
+template <typename TAP>
+__device__ __forceinline__ void bilinear_one(const TAP& tap, int cw, int ch, float xf, float yf, float* out, uint8_t* status)
+{
+    const double x = (double)xf, y = (double)yf;
+    const int fx = (int)x, fy = (int)y;
+    const double rx = x - fx, ry = y - fy;
+    const int tx[4] = { fx, fx, fx + 1, fx + 1 }, ty[4] = { fy, fy + 1, fy, fy + 1 };
+    const double wt[4] = { (1 - rx) * (1 - ry), (1 - rx) * ry, rx * (1 - ry), rx * ry };
+    float num[3] = { 0.f, 0.f, 0.f };
+    double den = 0.0;
+    int used = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (tx[k] >= cw || ty[k] >= ch) continue;
+        float p[3];
+        tap(tx[k], ty[k], p);
+        if (isinf(p[0]) || isinf(p[1]) || isinf(p[2])) continue;
+        const float wf = (float)wt[k];
+        for (int c = 0; c < 3; c++) num[c] = num[c] + wf * p[c];
+        den += wt[k];
+        used++;
+    }
+    if (!used) {
+        *status = 2;
+        out[0] = out[1] = out[2] = __builtin_nanf("");
+        return;
+    }
+    const float denf = (float)den;
+    bool nan = false;
+    for (int c = 0; c < 3; c++) {
+        out[c] = num[c] / denf;
+        nan |= isnan(out[c]);
+    }
+    *status = nan ? 1 : 0;
+}
+
+struct TapDisp {
+    const int16_t* disp16; int w, x0, y0; QMat Q;
+    __device__ void operator()(int x, int y, float* p) const
+    {
+        int gx = x + x0, gy = y + y0;
+        reproject_px(Q, gx, gy, (float)disp16[(size_t)gy * w + gx] / 16.0f, p);
+    }
+};
+struct TapImg {
+    const float* img; int w;
+    __device__ void operator()(int x, int y, float* p) const
+    {
+        const float* s = img + ((size_t)y * w + x) * 3;
+        p[0] = s[0]; p[1] = s[1]; p[2] = s[2];
+    }
+};
+
+__global__ void k_points3d(TapDisp tap, int cw, int ch, const float* __restrict__ xy, int n, float* __restrict__ xyz,
+                           uint8_t* __restrict__ status)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bilinear_one(tap, cw, ch, xy[2 * i], xy[2 * i + 1], xyz + 3 * (size_t)i, status + i);
+}
+__global__ void k_bilinear_img(TapImg tap, int cw, int ch, const float* __restrict__ xy, int n, float* __restrict__ xyz,
+                               uint8_t* __restrict__ status)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bilinear_one(tap, cw, ch, xy[2 * i], xy[2 * i + 1], xyz + 3 * (size_t)i, status + i);
+}
+
+static QMat make_q(const double* Q)
+{
+    QMat q;
+    memcpy(q.q, Q, sizeof(q.q));
+    return q;
+}
+
+int points3d_launch(vo_ctx* ctx, const int16_t* d_disp16, int w, int h, const float* d_xy, int n, float* d_xyz,
+                    uint8_t* d_status)
+{
+    if (!ctx->has_Q) return vo_fail(ctx, VO_E_STATE, "vo_set_Q has not been called");
+    int x0 = 0, y0 = 0, x1 = w, y1 = h;
+    if (ctx->has_roi) { x0 = ctx->roi[0]; y0 = ctx->roi[1]; x1 = ctx->roi[2] < w ? ctx->roi[2] : w; y1 = ctx->roi[3] < h ? ctx->roi[3] : h; }
+    if (n <= 0) return VO_OK;
+    TapDisp tap{ d_disp16, w, x0, y0, make_q(ctx->Q) };
+    hipLaunchKernelGGL(k_points3d, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, tap, x1 - x0, y1 - y0, d_xy, n, d_xyz, d_status);
+    VO_CHECK_LAUNCH(ctx);
+    return VO_OK;
+}
+
+extern "C" int vo_points3d_at(vo_ctx* ctx, int slot, const float* xy, int n, float* xyz_out, uint8_t* status_out)
+{
+    if (!ctx || slot < 0 || slot >= VO_NUM_SLOTS) return vo_fail(ctx, VO_E_ARG, "vo_points3d_at: bad slot");
+    FrameSlot& f = ctx->slots[slot];
+    if (!f.has_disp) return vo_fail(ctx, VO_E_STATE, "slot %d holds no disparity", slot);
+    if (n < 0 || n > ctx->kp_cap) return vo_fail(ctx, VO_E_CAP, "n=%d exceeds keypoint capacity %d", n, ctx->kp_cap);
+    if (n == 0) return VO_OK;
+    if (!xy || !xyz_out || !status_out) return vo_fail(ctx, VO_E_ARG, "vo_points3d_at: null pointer");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    // keypoints must lie inside the cropped image, as img[floor_y, floor_x] requires
+    int cw = (ctx->has_roi ? (ctx->roi[2] < f.w ? ctx->roi[2] : f.w) - ctx->roi[0] : f.w);
+    int chh = (ctx->has_roi ? (ctx->roi[3] < f.h ? ctx->roi[3] : f.h) - ctx->roi[1] : f.h);
+    for (int i = 0; i < n; i++)
+        if (!(xy[2 * i] >= 0 && xy[2 * i + 1] >= 0 && (int)xy[2 * i] < cw && (int)xy[2 * i + 1] < chh))
+            return vo_fail(ctx, VO_E_ARG, "keypoint %d (%g,%g) outside the %dx%d cropped image", i, xy[2 * i], xy[2 * i + 1], cw, chh);
+    VO_HIP(ctx, hipMemcpyAsync(ctx->xy_a, xy, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = points3d_launch(ctx, f.disp16, f.w, f.h, ctx->xy_a, n, ctx->pts_a, ctx->st_a);
+    if (rc) return rc;
+    VO_HIP(ctx, hipMemcpyAsync(xyz_out, ctx->pts_a, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(status_out, ctx->st_a, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+static int ensure_ws(vo_ctx* ctx, float** p, size_t* have, size_t bytes)
+{
+    if (*have >= bytes) return VO_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *have = 0;
+    VO_HIP(ctx, hipMalloc((void**)p, bytes));
+    *have = bytes;
+    return VO_OK;
+}
+
+extern "C" int vo_bilinear_at(vo_ctx* ctx, const float* img3d, int w, int h, const float* xy, int n, float* out,
+                              uint8_t* status_out)
+{
+    if (!ctx || !img3d || !xy || !out || !status_out || w <= 0 || h <= 0) return vo_fail(ctx, VO_E_ARG, "vo_bilinear_at: bad argument");
+    if (n < 0 || n > ctx->kp_cap) return vo_fail(ctx, VO_E_CAP, "n=%d exceeds keypoint capacity", n);
+    if (n == 0) return VO_OK;
+    for (int i = 0; i < n; i++)
+        if (!(xy[2 * i] >= 0 && xy[2 * i + 1] >= 0 && (int)xy[2 * i] < w && (int)xy[2 * i + 1] < h))
+            return vo_fail(ctx, VO_E_ARG, "point %d outside the image", i);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_ws(ctx, &ctx->img3_ws, &ctx->img3_ws_bytes, (size_t)w * h * 12);
+    if (rc) return rc;
+    VO_HIP(ctx, hipMemcpyAsync(ctx->img3_ws, img3d, (size_t)w * h * 12, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(ctx->xy_a, xy, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    TapImg tap{ ctx->img3_ws, w };
+    hipLaunchKernelGGL(k_bilinear_img, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, tap, w, h, ctx->xy_a, n, ctx->pts_a, ctx->st_a);
+    VO_CHECK_LAUNCH(ctx);
+    VO_HIP(ctx, hipMemcpyAsync(out, ctx->pts_a, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(status_out, ctx->st_a, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_reproject_to_3d(vo_ctx* ctx, const float* disp, int w, int h, const double* Q16, float* xyz)
+{
+    if (!ctx || !disp || !Q16 || !xyz || w <= 0 || h <= 0) return vo_fail(ctx, VO_E_ARG, "vo_reproject_to_3d: bad argument");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)w * h;
+    int rc = ensure_ws(ctx, &ctx->img3_ws, &ctx->img3_ws_bytes, n * 16);
+    if (rc) return rc;
+    float* d_disp = ctx->img3_ws + n * 3;
+    VO_HIP(ctx, hipMemcpyAsync(d_disp, disp, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_reproject, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, make_q(Q16), ctx->img3_ws);
+    VO_CHECK_LAUNCH(ctx);
+    VO_HIP(ctx, hipMemcpyAsync(xyz, ctx->img3_ws, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_download_xyz(vo_ctx* ctx, int slot, float* out)
+{
+    if (!ctx || slot < 0 || slot >= VO_NUM_SLOTS || !out) return vo_fail(ctx, VO_E_ARG, "vo_download_xyz: bad argument");
+    FrameSlot& f = ctx->slots[slot];
+    if (!f.has_disp) return vo_fail(ctx, VO_E_STATE, "slot %d holds no disparity", slot);
+    if (!ctx->has_Q) return vo_fail(ctx, VO_E_STATE, "vo_set_Q has not been called");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)f.w * f.h;
+    int rc = ensure_ws(ctx, &ctx->img3_ws, &ctx->img3_ws_bytes, n * 12);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_reproject_disp16, dim3(div_up(f.w, 256), f.h), dim3(256), 0, ctx->stream, f.disp16, f.w, f.h,
+                       make_q(ctx->Q), ctx->img3_ws);
+    VO_CHECK_LAUNCH(ctx);
+    VO_HIP(ctx, hipMemcpyAsync(out, ctx->img3_ws, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// ---- ratio test + fused point_clouds ----------------------------------------------------
+extern "C" int vo_ratio_filter(const int32_t* idx, const int32_t* dist, int nq, double ratio, int32_t* q_out,
+                               int32_t* t_out, int* m_out)
+{
+    if (!idx || !dist || !q_out || !t_out || !m_out || nq < 0) return VO_E_ARG;
+    int m = 0;
+    for (int i = 0; i < nq; i++) {
+        if (idx[2 * i + 1] < 0) return VO_E_ARG;  // the reference would raise IndexError (m[1] missing)
+        double a = (double)(float)dist[2 * i], b = (double)(float)dist[2 * i + 1];
+        if (a < ratio * b) { q_out[m] = i; t_out[m] = idx[2 * i]; m++; }
+    }
+    *m_out = m;
+    return VO_OK;
+}
+
+// ratio test + ordered compaction on the device: one wave, ballot prefix
+__global__ void k_ratio_compact(const int32_t* __restrict__ idx, const int32_t* __restrict__ dist, int nq, double ratio,
+                                const float* __restrict__ xy_q, const float* __restrict__ xy_t, int32_t* __restrict__ q_out,
+                                int32_t* __restrict__ t_out, float* __restrict__ xyq_out, float* __restrict__ xyt_out,
+                                int32_t* __restrict__ m_out)
+{
+    const int lane = threadIdx.x;
+    int base = 0;
+    for (int i0 = 0; i0 < nq; i0 += 64) {
+        int i = i0 + lane;
+        bool keep = false;
+        int t = -1;
+        if (i < nq) {
+            t = idx[2 * i];
+            double a = (double)(float)dist[2 * i], b = (double)(float)dist[2 * i + 1];
+            keep = idx[2 * i + 1] >= 0 && a < ratio * b;
+        }
+        unsigned long long bal = __ballot(keep);
+        if (keep) {
+            int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            q_out[pos] = i; t_out[pos] = t;
+            xyq_out[2 * pos] = xy_q[2 * i]; xyq_out[2 * pos + 1] = xy_q[2 * i + 1];
+            xyt_out[2 * pos] = xy_t[2 * t]; xyt_out[2 * pos + 1] = xy_t[2 * t + 1];
+        }
+        base += __popcll(bal);
+    }
+    if (lane == 0) *m_out = base;
+}
+
+extern "C" int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int32_t* q_idx, int32_t* t_idx,
+                               float* pts_a, float* pts_b, uint8_t* status_a, uint8_t* status_b, int cap, int* m_out)
+{
+    if (!ctx || slot_a < 0 || slot_a >= VO_NUM_SLOTS || slot_b < 0 || slot_b >= VO_NUM_SLOTS || !m_out)
+        return vo_fail(ctx, VO_E_ARG, "vo_point_clouds: bad argument");
+    FrameSlot& a = ctx->slots[slot_a];
+    FrameSlot& b = ctx->slots[slot_b];
+    if (!a.has_kp || !b.has_kp || !a.has_disp || !b.has_disp) return vo_fail(ctx, VO_E_STATE, "slots need disparity and keypoints");
+    *m_out = 0;
+    if (a.n_kp == 0) return VO_OK;
+    if (b.n_kp < 2) return vo_fail(ctx, VO_E_ARG, "train set has fewer than 2 descriptors (reference raises IndexError)");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    {
+        StageTimer t(ctx, VO_T_MATCH);
+        rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->m_idx, ctx->m_dist);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(64), 0, ctx->stream, ctx->m_idx, ctx->m_dist, a.n_kp, ratio, a.kp_xy,
+                           b.kp_xy, ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, ctx->counters);
+        VO_CHECK_LAUNCH(ctx);
+        // 3-D lookups for every query slot position (n_kp upper bound); only the first M are meaningful
+        VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->counters, 4, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const int m = *(int32_t*)ctx->pinned;
+    *m_out = m;
+    if (m == 0) return VO_OK;
+    {
+        StageTimer t(ctx, VO_T_POSE);
+        rc = points3d_launch(ctx, a.disp16, a.w, a.h, ctx->xy_a, m, ctx->pts_a, ctx->st_a);
+        if (rc) return rc;
+        rc = points3d_launch(ctx, b.disp16, b.w, b.h, ctx->xy_b, m, ctx->pts_b, ctx->st_b);
+        if (rc) return rc;
+    }
+    if (m > cap && (q_idx || t_idx || pts_a || pts_b || status_a || status_b))
+        return vo_fail(ctx, VO_E_CAP, "%d matches exceed output capacity %d", m, cap);
+    if (q_idx) VO_HIP(ctx, hipMemcpyAsync(q_idx, ctx->mq_idx, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (t_idx) VO_HIP(ctx, hipMemcpyAsync(t_idx, ctx->mt_idx, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (pts_a) VO_HIP(ctx, hipMemcpyAsync(pts_a, ctx->pts_a, (size_t)m * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (pts_b) VO_HIP(ctx, hipMemcpyAsync(pts_b, ctx->pts_b, (size_t)m * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (status_a) VO_HIP(ctx, hipMemcpyAsync(status_a, ctx->st_a, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    if (status_b) VO_HIP(ctx, hipMemcpyAsync(status_b, ctx->st_b, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// ---- Umeyama: two-pass float64 reductions on the device, 3x3 SVD on the host -------------
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// out[0..2] = sum src, out[3..5] = sum dst
+__global__ void k_umeyama_sums(const float* __restrict__ src, const float* __restrict__ dst, int m, double* __restrict__ out)
+{
+    __shared__ double sh[6][16];
+    double a[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int i = threadIdx.x; i < m; i += blockDim.x)
+        for (int c = 0; c < 3; c++) { a[c] += (double)src[3 * i + c]; a[3 + c] += (double)dst[3 * i + c]; }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = 0; c < 6; c++) { double s = wave_sum_f64(a[c]); if (lane == 0) sh[c][wv] = s; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double s = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) s += sh[threadIdx.x][k];
+        out[threadIdx.x] = s;
+    }
+}
+// out[6..14] = sum (dst-md)(src-ms)^T, out[15] = sum |src-ms|^2; means = out[0..5]/m
+__global__ void k_umeyama_cov(const float* __restrict__ src, const float* __restrict__ dst, int m, double* __restrict__ out)
+{
+    __shared__ double sh[10][16];
+    const double inv = 1.0 / m;
+    double ms[3], md[3];
+    for (int c = 0; c < 3; c++) { ms[c] = out[c] * inv; md[c] = out[3 + c] * inv; }
+    double a[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        double s[3], d[3];
+        for (int c = 0; c < 3; c++) { s[c] = (double)src[3 * i + c] - ms[c]; d[c] = (double)dst[3 * i + c] - md[c]; }
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) a[r * 3 + c] += d[r] * s[c];
+        a[9] += s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = 0; c < 10; c++) { double s = wave_sum_f64(a[c]); if (lane == 0) sh[c][wv] = s; }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        double s = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) s += sh[threadIdx.x][k];
+        out[6 + threadIdx.x] = s;
+    }
+}
+
+static void cross3(const double* a, const double* b, double* c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// one-sided Jacobi SVD of a 3x3 matrix (host); singular values descending
+void host_svd3(const double* A, double* U, double* w, double* Vt)
+{
+    double G[9], V[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    memcpy(G, A, sizeof(G));
+    for (int sweep = 0; sweep < 60; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double al = 0, be = 0, ga = 0;
+                for (int i = 0; i < 3; i++) {
+                    al += G[i * 3 + p] * G[i * 3 + p];
+                    be += G[i * 3 + q] * G[i * 3 + q];
+                    ga += G[i * 3 + p] * G[i * 3 + q];
+                }
+                if (fabs(ga) <= 1e-300 || fabs(ga) <= 2.2204460492503131e-16 * sqrt(al * be)) continue;
+                rotated = true;
+                double zeta = (be - al) / (2.0 * ga);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < 3; i++) {
+                    double gp = G[i * 3 + p], gq = G[i * 3 + q];
+                    G[i * 3 + p] = c * gp - s * gq;
+                    G[i * 3 + q] = s * gp + c * gq;
+                    double vp = V[i * 3 + p], vq = V[i * 3 + q];
+                    V[i * 3 + p] = c * vp - s * vq;
+                    V[i * 3 + q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sv[3];
+    int ord[3] = { 0, 1, 2 };
+    for (int j = 0; j < 3; j++) sv[j] = sqrt(G[j] * G[j] + G[3 + j] * G[3 + j] + G[6 + j] * G[6 + j]);
+    for (int i = 0; i < 2; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (sv[ord[j]] > sv[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    double Uc[3][3], Vc[3][3];
+    for (int j = 0; j < 3; j++) {
+        int o = ord[j];
+        w[j] = sv[o];
+        for (int i = 0; i < 3; i++) {
+            Vc[j][i] = V[i * 3 + o];
+            Uc[j][i] = sv[o] > 0 ? G[i * 3 + o] / sv[o] : 0.0;
+        }
+    }
+    const double tiny = w[0] * 1e-300 + 1e-300;
+    if (w[1] <= tiny) {
+        double a[3] = { 1, 0, 0 };
+        if (fabs(Uc[0][0]) > 0.9) { a[0] = 0; a[1] = 1; }
+        cross3(Uc[0], a, Uc[1]);
+        double nn = sqrt(Uc[1][0] * Uc[1][0] + Uc[1][1] * Uc[1][1] + Uc[1][2] * Uc[1][2]);
+        for (int i = 0; i < 3; i++) Uc[1][i] /= nn;
+    }
+    if (w[2] <= tiny || w[2] <= 1e-14 * w[0]) {
+        cross3(Uc[0], Uc[1], Uc[2]);
+        double nn = sqrt(Uc[2][0] * Uc[2][0] + Uc[2][1] * Uc[2][1] + Uc[2][2] * Uc[2][2]);
+        if (nn > 0) for (int i = 0; i < 3; i++) Uc[2][i] /= nn;
+    }
+    for (int j = 0; j < 3; j++)
+        for (int i = 0; i < 3; i++) { U[i * 3 + j] = Uc[j][i]; Vt[j * 3 + i] = Vc[j][i]; }
+}
+
+static double det3(const double* m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// finish Umeyama from the device sums (red[0..15])
+static int umeyama_finish(vo_ctx* ctx, const double* red, int m, int force_rotation, double* T, double* scale_out)
+{
+    const double inv = 1.0 / m;
+    double ms[3], md[3], cov[9];
+    for (int c = 0; c < 3; c++) { ms[c] = red[c] * inv; md[c] = red[3 + c] * inv; }
+    for (int k = 0; k < 9; k++) cov[k] = red[6 + k] * inv;
+    const double var_from = red[15];
+    double U[9], w[3], Vt[9];
+    host_svd3(cov, U, w, Vt);
+    // NaN inputs propagate to T (the reference then reports skip_cause "nan")
+    int nz = (w[0] != 0) + (w[1] != 0) + (w[2] != 0);
+    if (nz < 2) return vo_fail(ctx, VO_E_NUMERIC, "Points cannot be colinear");
+    double S[3] = { 1, 1, 1 };
+    if (force_rotation && det3(U) * det3(Vt) < 0) S[2] = -1;
+    double R[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += U[r * 3 + k] * S[k] * Vt[k * 3 + c];
+            R[r * 3 + c] = a;
+        }
+    double scale = (w[0] * S[0] + w[1] * S[1] + w[2] * S[2]) * ((double)m / var_from);
+    for (int r = 0; r < 3; r++) {
+        double nt = 0;
+        for (int c = 0; c < 3; c++) { T[r * 4 + c] = R[r * 3 + c]; nt += R[r * 3 + c] * ms[c]; }
+        T[r * 4 + 3] = md[r] - scale * nt;
+    }
+    if (scale_out) *scale_out = scale;
+    return VO_OK;
+}
+
+extern "C" int vo_umeyama(vo_ctx* ctx, const float* src, const float* dst, int m, int force_rotation, double* T12,
+                          double* scale_out)
+{
+    if (!ctx || !src || !dst || !T12) return vo_fail(ctx, VO_E_ARG, "vo_umeyama: bad argument");
+    if (m < 3) return vo_fail(ctx, VO_E_NUMERIC, "Umeyama algorithm needs at least 3 points for affine transformation estimation.");
+    if (m > ctx->kp_cap) return vo_fail(ctx, VO_E_CAP, "m=%d exceeds capacity %d", m, ctx->kp_cap);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    StageTimer t(ctx, VO_T_POSE);
+    VO_HIP(ctx, hipMemcpyAsync(ctx->pts_a, src, (size_t)m * 12, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(ctx->pts_b, dst, (size_t)m * 12, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_umeyama_sums, dim3(1), dim3(256), 0, ctx->stream, ctx->pts_a, ctx->pts_b, m, ctx->red);
+    hipLaunchKernelGGL(k_umeyama_cov, dim3(1), dim3(256), 0, ctx->stream, ctx->pts_a, ctx->pts_b, m, ctx->red);
+    VO_CHECK_LAUNCH(ctx);
+    VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->red, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return umeyama_finish(ctx, (const double*)ctx->pinned, m, force_rotation, T12, scale_out);
+}
+
+extern "C" int vo_rodrigues(const double* Rin, double* r)
+{
+    if (!Rin || !r) return VO_E_ARG;
+    double U[9], w[3], Vt[9], R[9];
+    host_svd3(Rin, U, w, Vt);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += U[i * 3 + k] * Vt[k * 3 + j];
+            R[i * 3 + j] = a;
+        }
+    r[0] = R[7] - R[5]; r[1] = R[2] - R[6]; r[2] = R[3] - R[1];
+    double s = sqrt((r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0; return VO_OK; }
+        double t = (R[0] + 1) * 0.5;
+        r[0] = sqrt(t > 0 ? t : 0);
+        t = (R[4] + 1) * 0.5;
+        r[1] = sqrt(t > 0 ? t : 0) * (R[1] < 0 ? -1. : 1.);
+        t = (R[8] + 1) * 0.5;
+        r[2] = sqrt(t > 0 ? t : 0) * (R[2] < 0 ? -1. : 1.);
+        if (fabs(r[0]) < fabs(r[1]) && fabs(r[0]) < fabs(r[2]) && (R[5] > 0) != (r[1] * r[2] > 0)) r[2] = -r[2];
+        theta /= sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        for (int i = 0; i < 3; i++) r[i] *= theta;
+    } else {
+        double vth = 1 / (2 * s) * theta;
+        for (int i = 0; i < 3; i++) r[i] *= vth;
+    }
+    return VO_OK;
+}
+
+// ---- rigid_body_filter: consistency matrix + greedy clique, one workgroup -----------------
+// cons[i][j] = | ||cur_i-cur_j|| - ||prev_i-prev_j|| | < thr, all in float32 as numpy evaluates it
+__global__ void k_rigid_cons(const float* __restrict__ prev, const float* __restrict__ cur, int m, float thr,
+                             uint8_t* __restrict__ cons, int* __restrict__ ncons)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= m) return;
+    float ax = cur[3 * i] - cur[3 * j], ay = cur[3 * i + 1] - cur[3 * j + 1], az = cur[3 * i + 2] - cur[3 * j + 2];
+    float bx = prev[3 * i] - prev[3 * j], by = prev[3 * i + 1] - prev[3 * j + 1], bz = prev[3 * i + 2] - prev[3 * j + 2];
+    float na = sqrtf((ax * ax + ay * ay) + az * az), nb = sqrtf((bx * bx + by * by) + bz * bz);
+    uint8_t c = fabsf(na - nb) < thr;
+    cons[(size_t)i * m + j] = c;
+    if (c) atomicAdd(&ncons[j], 1);  // column sums
+}
+
+__global__ void __launch_bounds__(1024) k_rigid_clique(const uint8_t* __restrict__ cons, const int* __restrict__ ncons, int m,
+                                                       int* __restrict__ clique, int* __restrict__ compat,
+                                                       long long* __restrict__ mask_out)
+{
+    __shared__ long long s_key[16];
+    __shared__ int s_sel, s_sum, s_stop;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    // block-wide argmax with first-max tie rule: key = value << 32 | (0x7fffffff - index), max
+    auto block_argmax = [&](long long key) -> int {
+        for (int o = 32; o > 0; o >>= 1) { long long other = __shfl_down(key, o, 64); key = other > key ? other : key; }
+        if (lane == 0) s_key[wv] = key;
+        __syncthreads();
+        if (tid == 0) {
+            long long k = s_key[0];
+            for (int q = 1; q < nw; q++) k = s_key[q] > k ? s_key[q] : k;
+            s_sel = 0x7fffffff - (int)(k & 0x7fffffffLL);
+        }
+        __syncthreads();
+        return s_sel;
+    };
+    // seed = argmax(num_consistent)
+    long long key = -0x7fffffffffffffffLL;
+    for (int j = tid; j < m; j += nt) {
+        long long k = ((long long)ncons[j] << 32) | (long long)(0x7fffffff - j);
+        key = k > key ? k : key;
+    }
+    const int seed = block_argmax(key);
+    for (int j = tid; j < m; j += nt) { clique[j] = j == seed; compat[j] = cons[(size_t)seed * m + j]; }
+    __syncthreads();
+    for (int it = 0; it < m; it++) {
+        // candidates = compatible - clique; stop when sum == 0; selected = argmax(ncons*cand)
+        int psum = 0;
+        key = -0x7fffffffffffffffLL;
+        for (int j = tid; j < m; j += nt) {
+            int cand = compat[j] - clique[j];
+            psum += cand;
+            long long v = (long long)ncons[j] * cand;
+            long long k = (v << 32) | (long long)(0x7fffffff - j);
+            key = k > key ? k : key;
+        }
+        if (tid == 0) s_sum = 0;
+        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) psum += __shfl_down(psum, o, 64);
+        if (lane == 0 && psum) atomicAdd(&s_sum, psum);
+        __syncthreads();
+        if (tid == 0) s_stop = (s_sum == 0);
+        __syncthreads();
+        if (s_stop) break;
+        const int sel = block_argmax(key);
+        if (tid == 0) clique[sel] = 1;
+        __syncthreads();
+        // csize = sum(clique)
+        int cs = 0;
+        for (int j = tid; j < m; j += nt) cs += clique[j];
+        if (tid == 0) s_sum = 0;
+        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) cs += __shfl_down(cs, o, 64);
+        if (lane == 0 && cs) atomicAdd(&s_sum, cs);
+        __syncthreads();
+        const int csize = s_sum;
+        __syncthreads();
+        // compatible[i] = (cons[i,:] . clique) >= csize   (one wave per row i)
+        for (int i = wv; i < m; i += nw) {
+            int dot = 0;
+            for (int j = lane; j < m; j += 64) dot += cons[(size_t)i * m + j] & clique[j];
+            for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
+            if (lane == 0) compat[i] = dot >= csize;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += nt) mask_out[j] = clique[j];
+}
+
+extern "C" int vo_rigid_clique(vo_ctx* ctx, const float* prev, const float* cur, int m, double thr, int64_t* mask_out)
+{
+    if (!ctx || !prev || !cur || !mask_out || m < 0) return vo_fail(ctx, VO_E_ARG, "vo_rigid_clique: bad argument");
+    if (m == 0) return VO_OK;
+    if (m > ctx->kp_cap) return vo_fail(ctx, VO_E_CAP, "m=%d exceeds capacity %d", m, ctx->kp_cap);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = (size_t)m * m + (size_t)m * 4 * 3 + (size_t)m * 8 + 1024;
+    if (ctx->clique_ws_bytes < need) {
+        if (ctx->clique_ws) (void)hipFree(ctx->clique_ws);
+        ctx->clique_ws = nullptr; ctx->clique_ws_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->clique_ws, need));
+        ctx->clique_ws_bytes = need;
+    }
+    StageTimer t(ctx, VO_T_POSE);
+    // carve: mask(8m) | ncons(4m) | clique(4m) | compat(4m) | cons(m*m)
+    long long* d_mask = (long long*)ctx->clique_ws;
+    int* d_ncons = (int*)(ctx->clique_ws + (size_t)m * 8);
+    int* d_clique = d_ncons + m;
+    int* d_compat = d_clique + m;
+    uint8_t* d_cons = (uint8_t*)(d_compat + m);
+    VO_HIP(ctx, hipMemcpyAsync(ctx->pts_a, prev, (size_t)m * 12, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(ctx->pts_b, cur, (size_t)m * 12, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipMemsetAsync(d_ncons, 0, (size_t)m * 4, ctx->stream));
+    hipLaunchKernelGGL(k_rigid_cons, dim3(div_up(m, 256), m), dim3(256), 0, ctx->stream, ctx->pts_a, ctx->pts_b, m, (float)thr, d_cons, d_ncons);
+    hipLaunchKernelGGL(k_rigid_clique, dim3(1), dim3(1024), 0, ctx->stream, d_cons, d_ncons, m, d_clique, d_compat, d_mask);
+    VO_CHECK_LAUNCH(ctx);
+    VO_HIP(ctx, hipMemcpyAsync(mask_out, d_mask, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}

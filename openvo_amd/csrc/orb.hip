@@ -1,0 +1,663 @@
+// ORB on gfx950: replaces cv2.ORB_create(nfeatures).detectAndCompute(img, mask)
+// [reference stereo_odometer.py:22,117] with the feature_mask of [stereo_odometer.py:38-41]
+// fused into the mask read.  Arithmetic definition: OpenCV 4.x features2d/src/orb.cpp,
+// fast.cpp, fast_score.cpp, keypoint.cpp with ORB_create's defaults (1.2f, 8 levels,
+// edgeThreshold 31, HARRIS_SCORE, patchSize 31, fastThreshold 20).  Integer stages are exact;
+// float stages (Harris response, IC angle, rotation) follow OpenCV's operation order and are
+// compiled without FMA contraction.  Keypoints are emitted in canonical (octave, y, x) order.
+//
+// Pyramid layout in HBM: one byte buffer per kind (image, blurred, mask, FAST score), level l
+// stored tightly (stride = level width) at lv[l].off.
+#include <math.h>
+#include "vo_internal.h"
+
+#define NL VO_ORB_LEVELS
+#define EDGE VO_ORB_EDGE
+#define HALF_PATCH VO_ORB_HALF_PATCH
+#define FAST_T 20
+
+struct LevelDev {
+    int w, h;
+    unsigned off;       // byte offset in pyramid buffers
+    float scale;
+    int quota;
+    int xt, yt;         // offsets into the resize tables (entries) for x and y
+    int min_x, max_x, min_y, max_y;
+    int cand_off;       // offset into candidate arrays
+};
+struct LevelsDev { LevelDev l[NL]; int umax[HALF_PATCH + 2]; };
+
+__constant__ int8_t c_pattern[1024] = {
+#include "../../include/vo_orb_pattern.inc"
+};
+
+// counters layout (int32)
+#define CNT_CAND 0
+#define CNT_A 8
+#define CNT_FIN 16
+#define CNT_TOTAL 24
+#define CNT_HIST 32
+
+// ---------------------------------------------------------------------------------------
+// host-side tables
+// ---------------------------------------------------------------------------------------
+static int cv_round_f(float v) { return (int)nearbyintf(v); }
+
+static void make_lin_coeffs(int srcsize, int dstsize, int32_t* ofs, uint16_t* coef, int* mn, int* mx)
+{
+    const double inv_scale = (double)dstsize / srcsize;
+    const double scale = 1.0 / inv_scale;
+    *mn = 0; *mx = dstsize;
+    for (int v = 0; v < dstsize; v++) {
+        volatile double t = scale * ((double)v + 0.5);
+        double fval = t - 0.5;
+        int ival = (int)floor(fval);
+        ofs[v] = 0; coef[2 * v] = 256; coef[2 * v + 1] = 0;
+        if (ival >= 0 && srcsize > 1) {
+            if (ival < srcsize - 1) {
+                ofs[v] = ival;
+                int c1 = (int)nearbyint((fval - (double)ival) * 256.0);
+                coef[2 * v + 1] = (uint16_t)c1;
+                coef[2 * v] = (uint16_t)(256 - c1);
+            } else {
+                ofs[v] = srcsize - 1;
+                if (v < *mx) *mx = v;
+            }
+        } else if (v + 1 > *mn)
+            *mn = v + 1;
+    }
+}
+
+
+int orb_prepare_tables(vo_ctx* ctx, int w, int h)
+{
+    if (ctx->orb_w == w && ctx->orb_h == h) return VO_OK;
+    LevelsDev L;
+    memset(&L, 0, sizeof(L));
+    std::vector<int32_t> ofs;
+    std::vector<uint16_t> coef;
+    size_t off = 0;
+    int cand_off = 0;
+    for (int l = 0; l < NL; l++) {
+        float scale = (float)pow((double)1.2f, (double)l);
+        float inv = 1.0f / scale;
+        LevelDev& d = L.l[l];
+        d.w = cv_round_f((float)w * inv);
+        d.h = cv_round_f((float)h * inv);
+        d.scale = scale;
+        d.off = (unsigned)off;
+        off += ((size_t)d.w * d.h + 255) & ~(size_t)255;
+        d.cand_off = cand_off;
+        cand_off += ((d.w + 1) / 2) * ((d.h + 1) / 2);
+        ctx->lv[l].w = d.w; ctx->lv[l].h = d.h; ctx->lv[l].off = d.off; ctx->lv[l].scale = scale;
+        if (l > 0) {
+            const LevelDev& p = L.l[l - 1];
+            d.xt = (int)ofs.size();
+            ofs.resize(ofs.size() + d.w); coef.resize(coef.size() + 2 * (size_t)d.w);
+            make_lin_coeffs(p.w, d.w, ofs.data() + d.xt, coef.data() + 2 * (size_t)d.xt, &d.min_x, &d.max_x);
+            d.yt = (int)ofs.size();
+            ofs.resize(ofs.size() + d.h); coef.resize(coef.size() + 2 * (size_t)d.h);
+            make_lin_coeffs(p.h, d.h, ofs.data() + d.yt, coef.data() + 2 * (size_t)d.yt, &d.min_y, &d.max_y);
+        }
+    }
+    if (off > ctx->pyr_bytes) return vo_fail(ctx, VO_E_CAP, "pyramid of %dx%d exceeds the context capacity", w, h);
+    if ((size_t)cand_off > (size_t)ctx->cand_cap * 4) return vo_fail(ctx, VO_E_CAP, "candidate capacity exceeded");
+    if (ofs.size() > (size_t)(ctx->max_w + ctx->max_h) * 2 * NL) return vo_fail(ctx, VO_E_CAP, "resize tables exceed capacity");
+    // umax: row half-widths of the circular patch (orb.cpp computeKeyPoints)
+    {
+        int vmax = (int)floor(HALF_PATCH * sqrt(2.f) / 2 + 1);
+        int vmin = (int)ceil(HALF_PATCH * sqrt(2.f) / 2);
+        for (int v = 0; v <= vmax; v++) L.umax[v] = (int)nearbyint(sqrt((double)HALF_PATCH * HALF_PATCH - v * v));
+        for (int v = HALF_PATCH, v0 = 0; v >= vmin; --v) {
+            while (L.umax[v0] == L.umax[v0 + 1]) ++v0;
+            L.umax[v] = v0;
+            ++v0;
+        }
+    }
+    VO_HIP(ctx, hipMemcpyAsync(ctx->rs_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(ctx->rs_coef, coef.data(), coef.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(ctx->d_levels, &L, sizeof(L), hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    static_assert(sizeof(LevelsDev) <= sizeof(ctx->rs_meta_host), "level table too large");
+    memcpy(ctx->rs_meta_host, &L, sizeof(L));
+    ctx->orb_quota_nfeatures = -1;
+    ctx->orb_w = w; ctx->orb_h = h;
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// pyramid
+// ---------------------------------------------------------------------------------------
+// level 0 = the cropped left image; mask level 0 from the disparity range (feature_mask) or an
+// explicit mask
+__global__ void k_orb_level0(const uint8_t* __restrict__ img, int img_stride, int w, int h, int mask_mode,
+                             const int16_t* __restrict__ disp16, int disp_stride, int min_d16, int max_d16,
+                             const uint8_t* __restrict__ mask, int mask_stride, uint8_t* __restrict__ pimg,
+                             uint8_t* __restrict__ pmask)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    pimg[(size_t)y * w + x] = img[(size_t)y * img_stride + x];
+    if (mask_mode == 1) {
+        int d = disp16[(size_t)y * disp_stride + x];
+        pmask[(size_t)y * w + x] = (d >= min_d16 && d <= max_d16) ? 255 : 0;
+    } else if (mask_mode == 2)
+        pmask[(size_t)y * w + x] = mask[(size_t)y * mask_stride + x];
+}
+
+__device__ __forceinline__ unsigned hrow(const uint8_t* __restrict__ s, int sw, int dx, const LevelDev& d,
+                                         const int32_t* __restrict__ xo, const uint16_t* __restrict__ xc)
+{
+    if (dx < d.min_x) return (unsigned)s[0] << 8;
+    if (dx >= d.max_x) return (unsigned)s[sw - 1] << 8;
+    const uint8_t* px = s + xo[dx];
+    return (unsigned)xc[2 * dx] * px[0] + (unsigned)xc[2 * dx + 1] * px[1];
+}
+
+// resize(prev, cur, INTER_LINEAR_EXACT) for image and (optionally) mask; mask then
+// threshold(254, THRESH_TOZERO)
+__global__ void k_orb_resize(const LevelsDev* __restrict__ L, int lvl, const int32_t* __restrict__ ofs,
+                             const uint16_t* __restrict__ coef, uint8_t* __restrict__ pimg, uint8_t* __restrict__ pmask,
+                             int with_mask)
+{
+    const LevelDev d = L->l[lvl];
+    const LevelDev p = L->l[lvl - 1];
+    int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (dx >= d.w) return;
+    const int32_t* xo = ofs + d.xt;
+    const uint16_t* xc = coef + 2 * (size_t)d.xt;
+    const int32_t* yo = ofs + d.yt;
+    const uint16_t* yc = coef + 2 * (size_t)d.yt;
+    for (int pass = 0; pass < (with_mask ? 2 : 1); pass++) {
+        const uint8_t* src = (pass ? pmask : pimg) + p.off;
+        uint8_t* dst = (pass ? pmask : pimg) + d.off;
+        unsigned out;
+        if (dy < d.min_y || dy >= d.max_y) {
+            const uint8_t* s = src + (size_t)(dy < d.min_y ? 0 : p.h - 1) * p.w;
+            out = (hrow(s, p.w, dx, d, xo, xc) + 128u) >> 8;
+        } else {
+            const uint8_t* s0 = src + (size_t)yo[dy] * p.w;
+            unsigned h0 = hrow(s0, p.w, dx, d, xo, xc), h1 = hrow(s0 + p.w, p.w, dx, d, xo, xc);
+            out = (h0 * (unsigned)yc[2 * dy] + h1 * (unsigned)yc[2 * dy + 1] + 32768u) >> 16;
+        }
+        if (pass) out = out > 254u ? out : 0u;
+        dst[(size_t)dy * d.w + dx] = (uint8_t)out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// FAST-9/16
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int w)
+{
+    // ring offsets (dx,dy), OpenCV order
+    const int rx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+    const int ry[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+    const int v = p[0];
+    int d[16];
+    unsigned dark = 0, bright = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int q = p[ry[k] * w + rx[k]];
+        d[k] = v - q;
+        dark |= (unsigned)(q < v - FAST_T) << k;
+        bright |= (unsigned)(q > v + FAST_T) << k;
+    }
+    // >= 9 contiguous set bits on the 16-ring
+    auto run9 = [](unsigned m) -> bool {
+        unsigned r = m | (m << 16);
+        unsigned a = r & (r >> 1);      // runs of 2
+        a = a & (a >> 2);               // runs of 4
+        a = a & (a >> 4);               // runs of 8
+        a = a & (r >> 8);               // runs of 9
+        return (a & 0xFFFFu) != 0;
+    };
+    if (!run9(dark) && !run9(bright)) return 0;
+    // cornerScore<16>: largest threshold for which the pixel is still a corner
+    int a0 = FAST_T;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int a = min(d[(k + 1) & 15], d[(k + 2) & 15]);
+#pragma unroll
+        for (int j = 3; j <= 8; j++) a = min(a, d[(k + j) & 15]);
+        a0 = max(a0, min(a, d[k & 15]));
+        a0 = max(a0, min(a, d[(k + 9) & 15]));
+    }
+    int b0 = -a0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int b = max(d[(k + 1) & 15], d[(k + 2) & 15]);
+#pragma unroll
+        for (int j = 3; j <= 8; j++) b = max(b, d[(k + j) & 15]);
+        b0 = min(b0, max(b, d[k & 15]));
+        b0 = min(b0, max(b, d[(k + 9) & 15]));
+    }
+    return -b0 - 1;
+}
+
+__global__ void k_orb_fast(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg, uint8_t* __restrict__ pscore)
+{
+    const LevelDev d = L->l[blockIdx.z];
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= d.w || y >= d.h) return;
+    int s = 0;
+    if (x >= 3 && x < d.w - 3 && y >= 3 && y < d.h - 3) s = fast_score_at(pimg + d.off + (size_t)y * d.w + x, d.w);
+    pscore[d.off + (size_t)y * d.w + x] = (uint8_t)s;
+}
+
+// 3x3 non-max suppression (strict >), pixel mask, image border; survivors appended per level
+__global__ void k_orb_nms(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pscore,
+                          const uint8_t* __restrict__ pmask, int with_mask, int32_t* __restrict__ cand_pos,
+                          float* __restrict__ cand_resp, int32_t* __restrict__ cnt)
+{
+    const int lvl = blockIdx.z;
+    const LevelDev d = L->l[lvl];
+    int x = blockIdx.x * blockDim.x + threadIdx.x + EDGE, y = blockIdx.y + EDGE;
+    if (d.w <= 2 * EDGE || d.h <= 2 * EDGE) return;
+    if (x >= d.w - EDGE || y >= d.h - EDGE) return;
+    const uint8_t* q = pscore + d.off + (size_t)y * d.w + x;
+    const int s = q[0], w = d.w;
+    if (!s) return;
+    if (!(s > q[-1] && s > q[1] && s > q[-w - 1] && s > q[-w] && s > q[-w + 1] && s > q[w - 1] && s > q[w] && s > q[w + 1])) return;
+    if (with_mask && pmask[d.off + (size_t)y * d.w + x] == 0) return;
+    int slot = atomicAdd(&cnt[CNT_CAND + lvl], 1);
+    cand_pos[d.cand_off + slot] = y * d.w + x;
+    cand_resp[d.cand_off + slot] = (float)s;
+    atomicAdd(&cnt[CNT_HIST + lvl * 256 + s], 1);
+}
+
+// retainBest(2*quota) by FAST score: keep every candidate whose score >= the n-th largest
+__global__ void __launch_bounds__(1024) k_orb_fast_select(const LevelsDev* __restrict__ L, const int32_t* __restrict__ cand_pos,
+                                                          const float* __restrict__ cand_resp, int32_t* __restrict__ candA_pos,
+                                                          int32_t* __restrict__ cnt)
+{
+    __shared__ int s_thr;
+    const int lvl = blockIdx.x;
+    const LevelDev d = L->l[lvl];
+    const int n = cnt[CNT_CAND + lvl], keep = 2 * d.quota;
+    if (threadIdx.x == 0) {
+        int thr = 0;
+        if (keep == 0) thr = 1 << 30;
+        else if (n > keep) {
+            int cum = 0;
+            for (int b = 255; b >= 0; b--) {
+                cum += cnt[CNT_HIST + lvl * 256 + b];
+                if (cum >= keep) { thr = b; break; }
+            }
+        }
+        s_thr = thr;
+    }
+    __syncthreads();
+    const int thr = s_thr;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        if ((int)cand_resp[d.cand_off + i] >= thr) {
+            int slot = atomicAdd(&cnt[CNT_A + lvl], 1);
+            candA_pos[d.cand_off + slot] = cand_pos[d.cand_off + i];
+        }
+}
+
+// Harris response (7x7 block) on the unblurred level
+__global__ void k_orb_harris(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg,
+                             const int32_t* __restrict__ candA_pos, float* __restrict__ candA_resp,
+                             const int32_t* __restrict__ cnt)
+{
+    const int lvl = blockIdx.y;
+    const LevelDev d = L->l[lvl];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt[CNT_A + lvl]) return;
+    const int pos = candA_pos[d.cand_off + i];
+    const int w = d.w;
+    const uint8_t* c = pimg + d.off + pos;
+    int a = 0, b = 0, cc = 0;
+    for (int dy = -3; dy <= 3; dy++)
+        for (int dx = -3; dx <= 3; dx++) {
+            const uint8_t* p = c + dy * w + dx;
+            int Ix = (p[1] - p[-1]) * 2 + (p[-w + 1] - p[-w - 1]) + (p[w + 1] - p[w - 1]);
+            int Iy = (p[w] - p[-w]) * 2 + (p[w - 1] - p[-w - 1]) + (p[w + 1] - p[-w + 1]);
+            a += Ix * Ix; b += Iy * Iy; cc += Ix * Iy;
+        }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale4 = scale * scale * scale * scale;
+    const float fa = (float)a, fb = (float)b, fc = (float)cc;
+    const float t1 = fa * fb, t2 = fc * fc, s = fa + fb;
+    const float t4 = (0.04f * s) * s;
+    candA_resp[d.cand_off + i] = ((t1 - t2) - t4) * scale4;
+}
+
+__device__ __forceinline__ unsigned f2key(float f)
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// retainBest(quota) by Harris response (radix select of the quota-th largest, ties kept), then
+// sort the survivors by position and stage them per level
+__global__ void __launch_bounds__(1024) k_orb_harris_select(const LevelsDev* __restrict__ L, const int32_t* __restrict__ candA_pos,
+                                                            const float* __restrict__ candA_resp, int32_t* __restrict__ fin_pos,
+                                                            float* __restrict__ fin_resp, int32_t* __restrict__ tmp_pos,
+                                                            float* __restrict__ tmp_resp, int32_t* __restrict__ cnt)
+{
+    __shared__ int hist[256];
+    __shared__ unsigned s_prefix, s_mask;
+    __shared__ int s_remaining, s_nf;
+    const int lvl = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const LevelDev d = L->l[lvl];
+    const int n = cnt[CNT_A + lvl], keep = d.quota;
+    const int32_t* pos = candA_pos + d.cand_off;
+    const float* resp = candA_resp + d.cand_off;
+    unsigned thr_key = 0;
+    if (keep <= 0) thr_key = 0xFFFFFFFFu;  // keep nothing (n_points == 0 clears)
+    else if (n > keep) {
+        if (tid == 0) { s_prefix = 0; s_mask = 0; s_remaining = keep; }
+        __syncthreads();
+        for (int pass = 3; pass >= 0; pass--) {
+            const int shift = pass * 8;
+            for (int b = tid; b < 256; b += nt) hist[b] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix, mask = s_mask;
+            for (int i = tid; i < n; i += nt) {
+                unsigned k = f2key(resp[i]);
+                if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, rem = s_remaining;
+                for (int b = 255; b >= 0; b--) {
+                    if (cum + hist[b] >= rem) { s_prefix = prefix | ((unsigned)b << shift); s_remaining = rem - cum; break; }
+                    cum += hist[b];
+                }
+                s_mask = mask | (255u << shift);
+            }
+            __syncthreads();
+        }
+        thr_key = s_prefix;
+    }
+    if (tid == 0) s_nf = 0;
+    __syncthreads();
+    int32_t* tp = tmp_pos + d.cand_off;
+    float* tr = tmp_resp + d.cand_off;
+    for (int i = tid; i < n; i += nt)
+        if (keep > 0 && f2key(resp[i]) >= thr_key) {
+            int slot = atomicAdd(&s_nf, 1);
+            tp[slot] = pos[i];
+            tr[slot] = resp[i];
+        }
+    __syncthreads();
+    const int nf = s_nf;
+    // canonical order: ascending position (rank by counting; positions are unique)
+    for (int i = tid; i < nf; i += nt) {
+        const int pi = tp[i];
+        int rank = 0;
+        for (int j = 0; j < nf; j++) rank += tp[j] < pi;
+        fin_pos[d.cand_off + rank] = pi;
+        fin_resp[d.cand_off + rank] = tr[i];
+    }
+    if (tid == 0) cnt[CNT_FIN + lvl] = nf;
+}
+
+// concatenate the levels into the slot's keypoint arrays
+__global__ void k_orb_pack(const LevelsDev* __restrict__ L, const int32_t* __restrict__ fin_pos,
+                           const float* __restrict__ fin_resp, int32_t* __restrict__ cnt, int cap, float* __restrict__ kp_xy,
+                           float* __restrict__ kp_size, float* __restrict__ kp_resp, int32_t* __restrict__ kp_oct,
+                           int32_t* __restrict__ kp_pos)
+{
+    const int lvl = blockIdx.y;
+    const LevelDev d = L->l[lvl];
+    int base = 0;
+    for (int k = 0; k < lvl; k++) base += cnt[CNT_FIN + k];
+    const int nf = cnt[CNT_FIN + lvl];
+    if (lvl == NL - 1 && blockIdx.x == 0 && threadIdx.x == 0) cnt[CNT_TOTAL] = base + nf;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf || base + i >= cap) return;
+    const int pos = fin_pos[d.cand_off + i];
+    const int x = pos % d.w, y = pos / d.w;
+    const int o = base + i;
+    kp_xy[2 * o] = (float)x * d.scale;
+    kp_xy[2 * o + 1] = (float)y * d.scale;
+    kp_size[o] = 31 * d.scale;
+    kp_resp[o] = fin_resp[d.cand_off + i];
+    kp_oct[o] = lvl;
+    kp_pos[o] = pos;
+}
+
+// ---------------------------------------------------------------------------------------
+// GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) as the sepFilter2D 8-bit path evaluates it:
+// kernel round(256*g) = [18,34,49,55,49,34,18], row pass exact in 16 bits, column pass
+// (sum + 2^15) >> 16 saturated.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+__constant__ int c_gk[7] = { 18, 34, 49, 55, 49, 34, 18 };
+
+__global__ void k_orb_blur_h(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg, uint16_t* __restrict__ tmp)
+{
+    const LevelDev d = L->l[blockIdx.z];
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= d.w || y >= d.h) return;
+    const uint8_t* r = pimg + d.off + (size_t)y * d.w;
+    int s = 0;
+#pragma unroll
+    for (int i = -3; i <= 3; i++) s += c_gk[i + 3] * r[reflect101(x + i, d.w)];
+    tmp[d.off + (size_t)y * d.w + x] = (uint16_t)s;
+}
+__global__ void k_orb_blur_v(const LevelsDev* __restrict__ L, const uint16_t* __restrict__ tmp, uint8_t* __restrict__ pblur)
+{
+    const LevelDev d = L->l[blockIdx.z];
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= d.w || y >= d.h) return;
+    int s = 0;
+#pragma unroll
+    for (int i = -3; i <= 3; i++) s += c_gk[i + 3] * (int)tmp[d.off + (size_t)reflect101(y + i, d.h) * d.w + x];
+    s = (s + (1 << 15)) >> 16;
+    pblur[d.off + (size_t)y * d.w + x] = (uint8_t)min(s, 255);
+}
+
+// ---------------------------------------------------------------------------------------
+// orientation (intensity centroid) + rotated BRIEF, one wave per keypoint
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg,
+                                                     const uint8_t* __restrict__ pblur, const int32_t* __restrict__ cnt, int cap,
+                                                     const float* __restrict__ kp_xy, const int32_t* __restrict__ kp_oct,
+                                                     const int32_t* __restrict__ kp_pos, float* __restrict__ kp_angle,
+                                                     uint8_t* __restrict__ desc)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int n = min(cnt[CNT_TOTAL], cap);
+    if (k >= n) return;
+    const int lvl = kp_oct[k];
+    const LevelDev d = L->l[lvl];
+    const int w = d.w, pos = kp_pos[k];
+    // intensity centroid over the circular patch: lanes 0..30 <-> u = lane-15
+    const uint8_t* ctr = pimg + d.off + pos;
+    int m10 = 0, m01 = 0;
+    const int u = lane - HALF_PATCH;
+    if (lane <= 2 * HALF_PATCH) {
+        const int au = abs(u);
+        for (int v = -HALF_PATCH; v <= HALF_PATCH; v++) {
+            if (au <= L->umax[abs(v)]) {
+                int val = ctr[v * w + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+    }
+    m10 = wave_sum_i32(m10);
+    m01 = wave_sum_i32(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    if (lane == 0) kp_angle[k] = angle;
+    // rotated BRIEF on the blurred level; lane j < 32 produces descriptor byte j
+    const float iscale = 1.f / d.scale;
+    const float ar = angle * (float)(3.1415926535897932384626433832795 / 180.f);
+    const float ca = (float)cos((double)ar), sa = (float)sin((double)ar);
+    const int cx = __float2int_rn(kp_xy[2 * k] * iscale), cy = __float2int_rn(kp_xy[2 * k + 1] * iscale);
+    const uint8_t* bc = pblur + d.off + (size_t)cy * w + cx;
+    if (lane < 32) {
+        int val = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const int8_t* pt = c_pattern + (lane * 8 + b) * 4;
+            const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+            const int ix0 = __float2int_rn(x0 * ca - y0 * sa), iy0 = __float2int_rn(x0 * sa + y0 * ca);
+            const int ix1 = __float2int_rn(x1 * ca - y1 * sa), iy1 = __float2int_rn(x1 * sa + y1 * ca);
+            const int t0 = bc[iy0 * w + ix0], t1 = bc[iy1 * w + ix1];
+            val |= (t0 < t1) << b;
+        }
+        desc[(size_t)k * 32 + lane] = (uint8_t)val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------
+int orb_run(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img_stride, int w, int h, int nfeatures, int mask_mode,
+            const int16_t* d_disp16, int disp_stride, int min_d16, int max_d16, const uint8_t* d_mask, int mask_stride)
+{
+    if (w < 2 * EDGE + 8 || h < 2 * EDGE + 8) {
+        // every level is cleared by runByImageBorder
+        fs->n_kp = 0; fs->has_kp = true;
+        return VO_OK;
+    }
+    int rc = orb_prepare_tables(ctx, w, h);
+    if (rc) return rc;
+    // per-level quotas (computeKeyPoints)
+    LevelsDev* Lh = (LevelsDev*)ctx->rs_meta_host;
+    {
+        float factor = (float)(1.0 / (double)1.2f);
+        float nd = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)NL));
+        int sum = 0;
+        for (int l = 0; l < NL - 1; l++) {
+            Lh->l[l].quota = cv_round_f(nd);
+            sum += Lh->l[l].quota;
+            nd *= factor;
+        }
+        Lh->l[NL - 1].quota = nfeatures - sum > 0 ? nfeatures - sum : 0;
+    }
+    if (ctx->orb_quota_nfeatures != nfeatures) {
+        VO_HIP(ctx, hipMemcpyAsync(ctx->d_levels, Lh, sizeof(LevelsDev), hipMemcpyHostToDevice, ctx->stream));
+        VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->orb_quota_nfeatures = nfeatures;
+    }
+    const LevelsDev* dL = (const LevelsDev*)ctx->d_levels;
+    const int with_mask = mask_mode != 0;
+    StageTimer t(ctx, VO_T_ORB);
+    VO_HIP(ctx, hipMemsetAsync(ctx->counters, 0, (CNT_HIST + NL * 256) * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(k_orb_level0, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_img, img_stride, w, h, mask_mode,
+                       d_disp16, disp_stride, min_d16, max_d16, d_mask, mask_stride, ctx->pyr_img, ctx->pyr_mask);
+    for (int l = 1; l < NL; l++)
+        hipLaunchKernelGGL(k_orb_resize, dim3(div_up(Lh->l[l].w, 256), Lh->l[l].h), dim3(256), 0, ctx->stream, dL, l, ctx->rs_ofs,
+                           ctx->rs_coef, ctx->pyr_img, ctx->pyr_mask, with_mask);
+    hipLaunchKernelGGL(k_orb_fast, dim3(div_up(w, 64), h, NL), dim3(64), 0, ctx->stream, dL, ctx->pyr_img, ctx->pyr_score);
+    hipLaunchKernelGGL(k_orb_nms, dim3(div_up(w - 2 * EDGE, 64), h - 2 * EDGE, NL), dim3(64), 0, ctx->stream, dL, ctx->pyr_score,
+                       ctx->pyr_mask, with_mask, ctx->cand_pos, ctx->cand_resp, ctx->counters);
+    hipLaunchKernelGGL(k_orb_fast_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->cand_pos, ctx->cand_resp, ctx->candA_pos, ctx->counters);
+    // upper bound of the Harris work list: every candidate of level 0
+    const int maxA = ((w + 1) / 2) * ((h + 1) / 2);
+    hipLaunchKernelGGL(k_orb_harris, dim3(div_up(maxA, 256), NL), dim3(256), 0, ctx->stream, dL, ctx->pyr_img, ctx->candA_pos,
+                       ctx->candA_resp, ctx->counters);
+    // after the select, cand_* hold the per-level final lists; candB_* are scratch
+    hipLaunchKernelGGL(k_orb_harris_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->candA_pos, ctx->candA_resp, ctx->cand_pos,
+                       ctx->cand_resp, ctx->candB_pos, ctx->candB_resp, ctx->counters);
+    hipLaunchKernelGGL(k_orb_pack, dim3(div_up(ctx->kp_cap, 256), NL), dim3(256), 0, ctx->stream, dL, ctx->cand_pos, ctx->cand_resp,
+                       ctx->counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, ctx->kp_pos);
+    hipLaunchKernelGGL(k_orb_blur_h, dim3(div_up(w, 256), h, NL), dim3(256), 0, ctx->stream, dL, ctx->pyr_img, ctx->pyr_tmp16);
+    hipLaunchKernelGGL(k_orb_blur_v, dim3(div_up(w, 256), h, NL), dim3(256), 0, ctx->stream, dL, ctx->pyr_tmp16, ctx->pyr_blur);
+    hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->pyr_img, ctx->pyr_blur,
+                       ctx->counters, ctx->kp_cap, fs->kp_xy, fs->kp_oct, ctx->kp_pos, fs->kp_angle, fs->desc);
+    VO_CHECK_LAUNCH(ctx);
+    VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->counters + CNT_TOTAL, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int total = *(int32_t*)ctx->pinned;
+    if (total > ctx->kp_cap)
+        return vo_fail(ctx, VO_E_CAP, "%d keypoints (response ties included) exceed capacity %d; raise max_kp", total, ctx->kp_cap);
+    fs->n_kp = total;
+    fs->has_kp = true;
+    return VO_OK;
+}
+
+static int download_kps(vo_ctx* ctx, FrameSlot& f, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
+                        int32_t* kp_octave, uint8_t* desc, int cap, int* n_out)
+{
+    const int n = f.n_kp;
+    if (n_out) *n_out = n;
+    if (n == 0) return VO_OK;
+    const bool any = kp_xy || kp_size || kp_angle || kp_response || kp_octave || desc;
+    if (any && n > cap) return vo_fail(ctx, VO_E_CAP, "%d keypoints exceed the output capacity %d", n, cap);
+    if (kp_xy) VO_HIP(ctx, hipMemcpyAsync(kp_xy, f.kp_xy, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (kp_size) VO_HIP(ctx, hipMemcpyAsync(kp_size, f.kp_size, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (kp_angle) VO_HIP(ctx, hipMemcpyAsync(kp_angle, f.kp_angle, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (kp_response) VO_HIP(ctx, hipMemcpyAsync(kp_response, f.kp_resp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (kp_octave) VO_HIP(ctx, hipMemcpyAsync(kp_octave, f.kp_oct, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (desc) VO_HIP(ctx, hipMemcpyAsync(desc, f.desc, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (any) VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_orb_detect_and_compute(vo_ctx* ctx, int slot, int nfeatures, int mask_mode, int min_disp16, int max_disp16,
+                                         float* kp_xy, float* kp_size, float* kp_angle, float* kp_response, int32_t* kp_octave,
+                                         uint8_t* desc, int cap, int* n_out)
+{
+    if (!ctx || slot < 0 || slot >= VO_NUM_SLOTS) return vo_fail(ctx, VO_E_ARG, "vo_orb_detect_and_compute: bad slot");
+    if (nfeatures < 0 || nfeatures > ctx->max_kp) return vo_fail(ctx, VO_E_CAP, "nfeatures %d exceeds max_kp %d", nfeatures, ctx->max_kp);
+    if (mask_mode != 0 && mask_mode != 1) return vo_fail(ctx, VO_E_ARG, "mask_mode must be 0 or 1");
+    FrameSlot& f = ctx->slots[slot];
+    if (!f.has_pair) return vo_fail(ctx, VO_E_STATE, "slot %d holds no image", slot);
+    if (mask_mode == 1 && !f.has_disp) return vo_fail(ctx, VO_E_STATE, "slot %d holds no disparity for the fused mask", slot);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    int x0 = 0, y0 = 0, x1 = f.w, y1 = f.h;
+    if (ctx->has_roi) { x0 = ctx->roi[0]; y0 = ctx->roi[1]; x1 = ctx->roi[2] < f.w ? ctx->roi[2] : f.w; y1 = ctx->roi[3] < f.h ? ctx->roi[3] : f.h; }
+    const int cw = x1 - x0, ch = y1 - y0;
+    if (cw <= 0 || ch <= 0) { f.n_kp = 0; f.has_kp = true; if (n_out) *n_out = 0; return VO_OK; }
+    int rc = orb_run(ctx, &f, f.left + (size_t)y0 * f.w + x0, f.w, cw, ch, nfeatures, mask_mode,
+                     f.disp16 + (size_t)y0 * f.w + x0, f.w, min_disp16, max_disp16, nullptr, 0);
+    if (rc) return rc;
+    return download_kps(ctx, f, kp_xy, kp_size, kp_angle, kp_response, kp_octave, desc, cap, n_out);
+}
+
+extern "C" int vo_orb_detect_and_compute_host(vo_ctx* ctx, const uint8_t* img, int w, int h, int stride, const uint8_t* mask,
+                                              int mask_stride, int nfeatures, float* kp_xy, float* kp_size, float* kp_angle,
+                                              float* kp_response, int32_t* kp_octave, uint8_t* desc, int cap, int* n_out)
+{
+    if (!ctx || !img || w <= 0 || h <= 0 || stride < w) return vo_fail(ctx, VO_E_ARG, "vo_orb_detect_and_compute_host: bad argument");
+    if (w > ctx->max_w || h > ctx->max_h) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context", w, h);
+    if (nfeatures < 0 || nfeatures > ctx->max_kp) return vo_fail(ctx, VO_E_CAP, "nfeatures %d exceeds max_kp %d", nfeatures, ctx->max_kp);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    FrameSlot& f = ctx->slots[VO_NUM_SLOTS];
+    VO_HIP(ctx, hipMemcpy2DAsync(f.left, w, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    if (mask) VO_HIP(ctx, hipMemcpy2DAsync(ctx->host_mask_dev, w, mask, mask_stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    int rc = orb_run(ctx, &f, f.left, w, w, h, nfeatures, mask ? 2 : 0, nullptr, 0, 0, 0, ctx->host_mask_dev, w);
+    if (rc) return rc;
+    return download_kps(ctx, f, kp_xy, kp_size, kp_angle, kp_response, kp_octave, desc, cap, n_out);
+}

@@ -1,0 +1,439 @@
+// Context, configuration, image front-end (cvtColor / remap), lazy downloads.
+// Replaces the cv2 calls of StereoCamera.compute_3d [reference stereo_camera.py:43-55].
+#include <stdarg.h>
+#include "vo_internal.h"
+
+int vo_fail(vo_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+static thread_local std::string g_create_err;
+
+template <typename T>
+static int dalloc(vo_ctx* ctx, T** p, size_t count)
+{
+    VO_HIP(ctx, hipMalloc((void**)p, count * sizeof(T) + 256));
+    return VO_OK;
+}
+#define DALLOC(p, n)                         \
+    do {                                     \
+        int rc__ = dalloc(ctx, &(p), (n));   \
+        if (rc__) { g_create_err = ctx->err; vo_destroy(ctx); return rc__; } \
+    } while (0)
+
+extern "C" const char* vo_last_error(const vo_ctx* ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int max_kp, vo_ctx** out)
+{
+    if (!out) return VO_E_ARG;
+    *out = nullptr;
+    if (max_w < 64 || max_h < 64 || max_disp < 16 || max_disp > 256 || max_disp % 16 || max_kp < 16) {
+        g_create_err = "vo_create: need max_w,max_h >= 64, 16 <= max_disp <= 256 (multiple of 16), max_kp >= 16";
+        return VO_E_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("vo_create: no HIP device available (") + hipGetErrorString(e) +
+                       "); libvo355 has no CPU fallback";
+        return VO_E_HIP;
+    }
+    if (device_id < 0 || device_id >= ndev) { g_create_err = "vo_create: bad device id"; return VO_E_ARG; }
+    vo_ctx* ctx = new vo_ctx();
+    ctx->device = device_id;
+    ctx->max_w = max_w; ctx->max_h = max_h; ctx->max_disp = max_disp; ctx->max_kp = max_kp;
+    if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s)", prop.name, prop.gcnArchName);
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+
+    const size_t npx = (size_t)max_w * max_h;
+    // keypoint capacity: OpenCV keeps response ties, so allow head-room over nfeatures
+    ctx->kp_cap = max_kp * 2 + 1024;
+    for (int s = 0; s <= VO_NUM_SLOTS; s++) {
+        FrameSlot& f = ctx->slots[s];
+        DALLOC(f.left, npx); DALLOC(f.right, npx); DALLOC(f.disp16, npx);
+        DALLOC(f.kp_xy, (size_t)ctx->kp_cap * 2); DALLOC(f.kp_size, ctx->kp_cap); DALLOC(f.kp_angle, ctx->kp_cap);
+        DALLOC(f.kp_resp, ctx->kp_cap); DALLOC(f.kp_oct, ctx->kp_cap); DALLOC(f.desc, (size_t)ctx->kp_cap * 32);
+    }
+    ctx->stage_bytes = npx * 3;
+    DALLOC(ctx->stage_in, ctx->stage_bytes * 2);
+    for (int c = 0; c < 2; c++) { DALLOC(ctx->map1[c], npx * 2); DALLOC(ctx->map2[c], npx); }
+    DALLOC(ctx->planesL, npx * 2); DALLOC(ctx->planesR, npx * 6);
+    ctx->vol_cells = npx * (size_t)max_disp;
+    DALLOC(ctx->C, ctx->vol_cells); DALLOC(ctx->S, ctx->vol_cells);
+    DALLOC(ctx->disp_raw, npx); DALLOC(ctx->ccl_label, npx); DALLOC(ctx->ccl_size, npx);
+    // ORB: 8-level pyramid is < 3.2x the base image
+    ctx->pyr_bytes = npx * 4;
+    DALLOC(ctx->pyr_img, ctx->pyr_bytes); DALLOC(ctx->pyr_blur, ctx->pyr_bytes);
+    DALLOC(ctx->pyr_mask, ctx->pyr_bytes); DALLOC(ctx->pyr_score, ctx->pyr_bytes);
+    DALLOC(ctx->rs_ofs, (size_t)(max_w + max_h) * 2 * VO_ORB_LEVELS);
+    DALLOC(ctx->rs_coef, (size_t)(max_w + max_h) * 4 * VO_ORB_LEVELS);
+    DALLOC(ctx->rs_meta, 64 * VO_ORB_LEVELS);
+    VO_HIP(ctx, hipMalloc(&ctx->d_levels, 4096));
+    // FAST candidates after NMS are never 8-adjacent: at most ceil(w/2)*ceil(h/2) per level
+    ctx->cand_cap = (int)((size_t)((max_w + 1) / 2) * ((max_h + 1) / 2));
+    // (summed over the 8 levels: < 3.2x that)
+    DALLOC(ctx->cand_pos, (size_t)ctx->cand_cap * 4); DALLOC(ctx->cand_resp, (size_t)ctx->cand_cap * 4);
+    DALLOC(ctx->candA_pos, (size_t)ctx->cand_cap * 4); DALLOC(ctx->candA_resp, (size_t)ctx->cand_cap * 4);
+    DALLOC(ctx->candB_pos, (size_t)ctx->cand_cap * 4); DALLOC(ctx->candB_resp, (size_t)ctx->cand_cap * 4);
+    DALLOC(ctx->kp_pos, ctx->kp_cap); DALLOC(ctx->pyr_tmp16, ctx->pyr_bytes);
+    DALLOC(ctx->counters, 8192);
+    DALLOC(ctx->host_mask_dev, npx);
+    DALLOC(ctx->mq, (size_t)ctx->kp_cap * 32); DALLOC(ctx->mt, (size_t)ctx->kp_cap * 32);
+    DALLOC(ctx->m_idx, (size_t)ctx->kp_cap * 2); DALLOC(ctx->m_dist, (size_t)ctx->kp_cap * 2);
+    DALLOC(ctx->pts_a, (size_t)ctx->kp_cap * 3); DALLOC(ctx->pts_b, (size_t)ctx->kp_cap * 3);
+    DALLOC(ctx->st_a, ctx->kp_cap); DALLOC(ctx->st_b, ctx->kp_cap);
+    DALLOC(ctx->xy_a, (size_t)ctx->kp_cap * 2); DALLOC(ctx->xy_b, (size_t)ctx->kp_cap * 2);
+    DALLOC(ctx->mq_idx, ctx->kp_cap); DALLOC(ctx->mt_idx, ctx->kp_cap);
+    DALLOC(ctx->red, 4096);
+    ctx->pinned_bytes = 1 << 20;
+    if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+        g_create_err = "hipHostMalloc failed"; vo_destroy(ctx); return VO_E_HIP;
+    }
+    *out = ctx;
+    return VO_OK;
+}
+
+extern "C" void vo_destroy(vo_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int s = 0; s <= VO_NUM_SLOTS; s++) {
+        FrameSlot& f = ctx->slots[s];
+        void* ps[] = { f.left, f.right, f.disp16, f.kp_xy, f.kp_size, f.kp_angle, f.kp_resp, f.kp_oct, f.desc };
+        for (void* p : ps) if (p) (void)hipFree(p);
+    }
+    void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
+                   ctx->C, ctx->S, ctx->disp_raw, ctx->ccl_label, ctx->ccl_size, ctx->pyr_img, ctx->pyr_blur,
+                   ctx->pyr_mask, ctx->pyr_score, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->cand_pos,
+                   ctx->cand_resp, ctx->candA_pos, ctx->candA_resp, ctx->candB_pos, ctx->candB_resp, ctx->kp_pos, ctx->pyr_tmp16, ctx->counters, ctx->host_mask_dev, ctx->mq, ctx->mt,
+                   ctx->m_idx, ctx->m_dist, ctx->pts_a, ctx->pts_b, ctx->st_a, ctx->st_b, ctx->xy_a, ctx->xy_b,
+                   ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws };
+    for (void* p : ps) if (p) (void)hipFree(p);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int vo_device_name(const vo_ctx* ctx, char* buf, int buflen)
+{
+    if (!ctx || !buf || buflen <= 0) return VO_E_ARG;
+    snprintf(buf, buflen, "%s", ctx->devname);
+    return VO_OK;
+}
+
+extern "C" int vo_synchronize(vo_ctx* ctx)
+{
+    if (!ctx) return VO_E_ARG;
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_set_rectify_maps(vo_ctx* ctx, int cam, const int16_t* map1, const uint16_t* map2, int w, int h)
+{
+    if (!ctx || cam < 0 || cam > 1 || !map1 || !map2) return vo_fail(ctx, VO_E_ARG, "vo_set_rectify_maps: bad argument");
+    if (w > ctx->max_w || h > ctx->max_h || w <= 0 || h <= 0) return vo_fail(ctx, VO_E_CAP, "maps %dx%d exceed context %dx%d", w, h, ctx->max_w, ctx->max_h);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    VO_HIP(ctx, hipMemcpyAsync(ctx->map1[cam], map1, (size_t)w * h * 4, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(ctx->map2[cam], map2, (size_t)w * h * 2, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->map_w = w; ctx->map_h = h; ctx->has_map[cam] = true;
+    return VO_OK;
+}
+
+extern "C" int vo_set_sgbm(vo_ctx* ctx, int minDisparity, int numDisparities, int blockSize, int P1, int P2,
+                           int disp12MaxDiff, int preFilterCap, int uniquenessRatio, int speckleWindowSize,
+                           int speckleRange, int mode)
+{
+    if (!ctx) return VO_E_ARG;
+    if (numDisparities <= 0 || numDisparities % 16) return vo_fail(ctx, VO_E_ARG, "numDisparities must be a positive multiple of 16");
+    if (numDisparities > ctx->max_disp) return vo_fail(ctx, VO_E_CAP, "numDisparities %d > max_disp %d", numDisparities, ctx->max_disp);
+    if (mode != 0 && mode != 1) return vo_fail(ctx, VO_E_ARG, "mode must be 0 (MODE_SGBM) or 1 (MODE_HH)");
+    // effective parameters exactly as computeDisparitySGBM derives them
+    SgbmEff& e = ctx->sg;
+    e.minD = minDisparity; e.D = numDisparities; e.maxD = minDisparity + numDisparities;
+    e.ur = uniquenessRatio >= 0 ? uniquenessRatio : 10;
+    e.d12 = disp12MaxDiff > 0 ? disp12MaxDiff : 1;
+    e.P1 = P1 > 0 ? P1 : 2;
+    int p2 = P2 > 0 ? P2 : 5;
+    e.P2 = p2 > e.P1 + 1 ? p2 : e.P1 + 1;
+    int bs = blockSize > 0 ? blockSize : 5;
+    e.SW2 = e.SH2 = bs / 2;
+    e.ftzero = (preFilterCap > 15 ? preFilterCap : 15) | 1;
+    e.speckleWindow = speckleWindowSize; e.speckleRange = speckleRange; e.mode = mode;
+    if (e.SW2 > 5) return vo_fail(ctx, VO_E_ARG, "blockSize > 11 is not supported");
+    if (e.P2 > 8000 || e.ftzero > 127) return vo_fail(ctx, VO_E_ARG, "P2 > 8000 or preFilterCap > 127 would overflow int16 costs");
+    e.set = true;
+    return VO_OK;
+}
+
+extern "C" int vo_set_Q(vo_ctx* ctx, const double* Q16)
+{
+    if (!ctx || !Q16) return VO_E_ARG;
+    memcpy(ctx->Q, Q16, sizeof(ctx->Q));
+    ctx->has_Q = true;
+    return VO_OK;
+}
+
+extern "C" int vo_set_roi(vo_ctx* ctx, int x0, int y0, int x1, int y1)
+{
+    if (!ctx) return VO_E_ARG;
+    if (x0 < 0 || y0 < 0) return vo_fail(ctx, VO_E_ARG, "negative ROI origin is not supported");
+    ctx->roi[0] = x0; ctx->roi[1] = y0; ctx->roi[2] = x1; ctx->roi[3] = y1;
+    ctx->has_roi = true;
+    return VO_OK;
+}
+
+// ---- cvtColor BGR2GRAY (OpenCV 4.x RGB2Gray<uchar>, 15-bit coefficients) -------------
+__global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, int n, uint8_t* __restrict__ gray)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int b = bgr[3 * (size_t)i], g = bgr[3 * (size_t)i + 1], r = bgr[3 * (size_t)i + 2];
+    gray[i] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+}
+
+// ---- remap INTER_LINEAR with CV_16SC2 + fractional maps, border constant 0 ------------
+__global__ void k_remap(const uint8_t* __restrict__ src, int sw, int sh, const int16_t* __restrict__ map1,
+                        const uint16_t* __restrict__ map2, int w, int h, uint8_t* __restrict__ dst)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    size_t i = (size_t)y * w + x;
+    int sx = map1[2 * i], sy = map1[2 * i + 1];
+    int f = map2[i] & 1023, fx = f & 31, fy = f >> 5;
+    int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    int p00 = 0, p01 = 0, p10 = 0, p11 = 0;
+    bool x0ok = (unsigned)sx < (unsigned)sw, x1ok = (unsigned)(sx + 1) < (unsigned)sw;
+    if ((unsigned)sy < (unsigned)sh) {
+        if (x0ok) p00 = src[(size_t)sy * sw + sx];
+        if (x1ok) p01 = src[(size_t)sy * sw + sx + 1];
+    }
+    if ((unsigned)(sy + 1) < (unsigned)sh) {
+        if (x0ok) p10 = src[(size_t)(sy + 1) * sw + sx];
+        if (x1ok) p11 = src[(size_t)(sy + 1) * sw + sx + 1];
+    }
+    int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+    dst[i] = (uint8_t)min(v, 255);
+}
+
+static int check_slot(vo_ctx* ctx, int slot)
+{
+    if (!ctx) return VO_E_ARG;
+    if (slot < 0 || slot >= VO_NUM_SLOTS) return vo_fail(ctx, VO_E_ARG, "slot %d out of range [0,%d)", slot, VO_NUM_SLOTS);
+    return VO_OK;
+}
+
+// upload one camera image into dst (gray, rectified)
+static int ingest(vo_ctx* ctx, int cam, const uint8_t* host, int w, int h, int channels, int preprocessed, uint8_t* dst,
+                  uint8_t* stage)
+{
+    const size_t n = (size_t)w * h;
+    const bool need_remap = !preprocessed;
+    if (need_remap && (!ctx->has_map[cam] || ctx->map_w != w || ctx->map_h != h))
+        return vo_fail(ctx, VO_E_STATE, "rectification maps for camera %d not set for %dx%d", cam, w, h);
+    uint8_t* gray = need_remap ? stage + n * 3 : dst;  // gray staging behind the colour staging
+    if (channels == 3) {
+        VO_HIP(ctx, hipMemcpyAsync(stage, host, n * 3, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_bgr2gray, dim3(div_up((int)n, 256)), dim3(256), 0, ctx->stream, stage, (int)n, gray);
+    } else {
+        VO_HIP(ctx, hipMemcpyAsync(gray, host, n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (need_remap)
+        hipLaunchKernelGGL(k_remap, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, gray, w, h, ctx->map1[cam],
+                           ctx->map2[cam], w, h, dst);
+    VO_CHECK_LAUNCH(ctx);
+    return VO_OK;
+}
+
+extern "C" int vo_upload_pair(vo_ctx* ctx, int slot, const uint8_t* left, const uint8_t* right, int w, int h,
+                              int channels, int preprocessed)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (!left || !right || (channels != 1 && channels != 3)) return vo_fail(ctx, VO_E_ARG, "vo_upload_pair: bad argument");
+    if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context %dx%d", w, h, ctx->max_w, ctx->max_h);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    FrameSlot& f = ctx->slots[slot];
+    StageTimer t(ctx, VO_T_UPLOAD);
+    // the two cameras use disjoint halves of the staging buffer (4 bytes/pixel each would be
+    // needed for colour + gray; stage_in holds 6 bytes/pixel)
+    rc = ingest(ctx, 0, left, w, h, channels, preprocessed, f.left, ctx->stage_in);
+    if (rc) return rc;
+    // the second ingest reuses the staging area: order on the stream makes that safe
+    rc = ingest(ctx, 1, right, w, h, channels, preprocessed, f.right, ctx->stage_in);
+    if (rc) return rc;
+    f.w = w; f.h = h; f.has_pair = true; f.has_disp = false; f.has_kp = false; f.n_kp = 0;
+    return VO_OK;
+}
+
+extern "C" int vo_sgbm_compute(vo_ctx* ctx, int slot, int16_t* disp16_out)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    FrameSlot& f = ctx->slots[slot];
+    if (!f.has_pair) return vo_fail(ctx, VO_E_STATE, "slot %d holds no image pair", slot);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    rc = sgbm_run(ctx, f.left, f.right, f.w, f.h, f.disp16);
+    if (rc) return rc;
+    f.has_disp = true;
+    if (disp16_out) {
+        VO_HIP(ctx, hipMemcpyAsync(disp16_out, f.disp16, (size_t)f.w * f.h * 2, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_sgbm_compute_host(vo_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, int16_t* disp16_out)
+{
+    if (!ctx || !left || !right || !disp16_out) return vo_fail(ctx, VO_E_ARG, "vo_sgbm_compute_host: bad argument");
+    if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context", w, h);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    FrameSlot& f = ctx->slots[VO_NUM_SLOTS];
+    VO_HIP(ctx, hipMemcpyAsync(f.left, left, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(f.right, right, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
+    int rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
+    if (rc) return rc;
+    VO_HIP(ctx, hipMemcpyAsync(disp16_out, f.disp16, (size_t)w * h * 2, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_cvt_bgr2gray(vo_ctx* ctx, const uint8_t* bgr, int w, int h, uint8_t* gray)
+{
+    if (!ctx || !bgr || !gray) return vo_fail(ctx, VO_E_ARG, "vo_cvt_bgr2gray: bad argument");
+    if ((size_t)w * h > (size_t)ctx->max_w * ctx->max_h) return vo_fail(ctx, VO_E_CAP, "image too large");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)w * h;
+    VO_HIP(ctx, hipMemcpyAsync(ctx->stage_in, bgr, n * 3, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_bgr2gray, dim3(div_up((int)n, 256)), dim3(256), 0, ctx->stream, ctx->stage_in, (int)n, ctx->stage_in + n * 3);
+    VO_CHECK_LAUNCH(ctx);
+    VO_HIP(ctx, hipMemcpyAsync(gray, ctx->stage_in + n * 3, n, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_remap(vo_ctx* ctx, int cam, const uint8_t* src, int w, int h, uint8_t* dst)
+{
+    if (!ctx || !src || !dst || cam < 0 || cam > 1) return vo_fail(ctx, VO_E_ARG, "vo_remap: bad argument");
+    if (!ctx->has_map[cam]) return vo_fail(ctx, VO_E_STATE, "maps of camera %d not set", cam);
+    if ((size_t)w * h > (size_t)ctx->max_w * ctx->max_h) return vo_fail(ctx, VO_E_CAP, "image too large");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)w * h, nm = (size_t)ctx->map_w * ctx->map_h;
+    VO_HIP(ctx, hipMemcpyAsync(ctx->stage_in, src, n, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t* out = ctx->stage_in + ctx->stage_bytes;
+    hipLaunchKernelGGL(k_remap, dim3(div_up(ctx->map_w, 256), ctx->map_h), dim3(256), 0, ctx->stream, ctx->stage_in, w, h,
+                       ctx->map1[cam], ctx->map2[cam], ctx->map_w, ctx->map_h, out);
+    VO_CHECK_LAUNCH(ctx);
+    VO_HIP(ctx, hipMemcpyAsync(dst, out, nm, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// ---- lazy downloads ---------------------------------------------------------------------
+__global__ void k_disp_to_f32(const int16_t* __restrict__ d, int n, float* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)d[i] / 16.0f;
+}
+
+static int ensure_img3(vo_ctx* ctx, size_t bytes)
+{
+    if (ctx->img3_ws_bytes >= bytes) return VO_OK;
+    if (ctx->img3_ws) (void)hipFree(ctx->img3_ws);
+    ctx->img3_ws = nullptr; ctx->img3_ws_bytes = 0;
+    VO_HIP(ctx, hipMalloc((void**)&ctx->img3_ws, bytes));
+    ctx->img3_ws_bytes = bytes;
+    return VO_OK;
+}
+
+extern "C" int vo_download_disparity_f32(vo_ctx* ctx, int slot, float* out)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    FrameSlot& f = ctx->slots[slot];
+    if (!f.has_disp || !out) return vo_fail(ctx, VO_E_STATE, "slot %d holds no disparity", slot);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    const int n = f.w * f.h;
+    if ((rc = ensure_img3(ctx, (size_t)n * 12))) return rc;
+    hipLaunchKernelGGL(k_disp_to_f32, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, f.disp16, n, ctx->img3_ws);
+    VO_CHECK_LAUNCH(ctx);
+    VO_HIP(ctx, hipMemcpyAsync(out, ctx->img3_ws, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_download_left(vo_ctx* ctx, int slot, uint8_t* out)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    FrameSlot& f = ctx->slots[slot];
+    if (!f.has_pair || !out) return vo_fail(ctx, VO_E_STATE, "slot %d holds no image", slot);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    VO_HIP(ctx, hipMemcpyAsync(out, f.left, (size_t)f.w * f.h, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_download_right(vo_ctx* ctx, int slot, uint8_t* out)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    FrameSlot& f = ctx->slots[slot];
+    if (!f.has_pair || !out) return vo_fail(ctx, VO_E_STATE, "slot %d holds no image", slot);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    VO_HIP(ctx, hipMemcpyAsync(out, f.right, (size_t)f.w * f.h, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_slot_num_keypoints(vo_ctx* ctx, int slot, int* n_out)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (!n_out) return VO_E_ARG;
+    *n_out = ctx->slots[slot].has_kp ? ctx->slots[slot].n_kp : 0;
+    return VO_OK;
+}
+
+extern "C" int vo_enable_timing(vo_ctx* ctx, int on)
+{
+    if (!ctx) return VO_E_ARG;
+    ctx->timing = on != 0;
+    return VO_OK;
+}
+
+extern "C" int vo_get_timings(vo_ctx* ctx, double* ms_out, int64_t* launches_out, int reset)
+{
+    if (!ctx) return VO_E_ARG;
+    for (int i = 0; i < VO_T_NSTAGES; i++) {
+        if (ms_out) ms_out[i] = ctx->t_ms[i];
+        if (launches_out) launches_out[i] = ctx->t_n[i];
+        if (reset) { ctx->t_ms[i] = 0; ctx->t_n[i] = 0; }
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_sgbm_last_geometry(vo_ctx* ctx, int64_t* cells, int* n_paths)
+{
+    if (!ctx) return VO_E_ARG;
+    if (cells) *cells = ctx->last_cells;
+    if (n_paths) *n_paths = ctx->last_paths;
+    return VO_OK;
+}

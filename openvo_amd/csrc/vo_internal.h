@@ -1,0 +1,177 @@
+// Internal declarations of libvo355 (gfx950 only).  See include/vo355.h for the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/vo355.h"
+
+#define VO_ORB_LEVELS 8
+#define VO_ORB_EDGE 31
+#define VO_ORB_HALF_PATCH 15
+
+struct SgbmEff {
+    int minD, maxD, D, ur, d12, P1, P2, SW2, SH2, ftzero, minX1, maxX1, W1, invalid16;
+    int speckleWindow, speckleRange, mode;
+    bool set;
+};
+
+struct OrbLevel {
+    int w, h;            // level size
+    size_t off;          // byte offset of the level inside the pyramid buffers
+    float scale;         // 1.2^l as float
+    int quota;           // filled per call (depends on nfeatures)
+};
+
+struct FrameSlot {
+    uint8_t* left = nullptr;    // rectified gray, max_w*max_h
+    uint8_t* right = nullptr;
+    int16_t* disp16 = nullptr;  // max_w*max_h
+    // keypoints (device), capacity kp_cap
+    float* kp_xy = nullptr;
+    float* kp_size = nullptr;
+    float* kp_angle = nullptr;
+    float* kp_resp = nullptr;
+    int32_t* kp_oct = nullptr;
+    uint8_t* desc = nullptr;
+    int n_kp = 0;
+    int w = 0, h = 0;
+    bool has_pair = false, has_disp = false, has_kp = false;
+};
+
+struct vo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;
+    std::string err;
+    char devname[256] = {0};
+
+    SgbmEff sg{};
+    double Q[16];
+    bool has_Q = false;
+    int roi[4] = {0, 0, 0, 0};
+    bool has_roi = false;
+
+    // rectification maps
+    int16_t* map1[2] = {nullptr, nullptr};
+    uint16_t* map2[2] = {nullptr, nullptr};
+    int map_w = 0, map_h = 0;
+    bool has_map[2] = {false, false};
+
+    FrameSlot slots[VO_NUM_SLOTS + 1];  // last slot = scratch for the *_host seams
+
+    // staging
+    uint8_t* stage_in = nullptr;   // raw upload (max_w*max_h*3)
+    size_t stage_bytes = 0;
+
+    // SGBM workspace
+    uint32_t* planesL = nullptr;   // per pixel 2 x u32 (u,u0,u1 for both channels)
+    uint32_t* planesR = nullptr;   // per pixel 6 x u32 pair-packed (v,v0,v1 x 2 channels)
+    int16_t* C = nullptr;          // cost volume
+    int16_t* S = nullptr;          // aggregated volume
+    size_t vol_cells = 0;
+    int16_t* disp_raw = nullptr;
+    int32_t* ccl_label = nullptr;
+    int32_t* ccl_size = nullptr;
+    int64_t last_cells = 0;
+    int last_paths = 0;
+
+    // ORB workspace
+    OrbLevel lv[VO_ORB_LEVELS];
+    int orb_w = 0, orb_h = 0;      // geometry the pyramid tables were built for
+    size_t pyr_bytes = 0;
+    uint8_t* pyr_img = nullptr;    // all levels, unblurred
+    uint8_t* pyr_blur = nullptr;
+    uint8_t* pyr_mask = nullptr;
+    uint8_t* pyr_score = nullptr;  // FAST scores before NMS
+    int32_t* rs_ofs = nullptr;     // resize tables (all levels): x then y offsets
+    uint16_t* rs_coef = nullptr;
+    int32_t* rs_meta = nullptr;    // per level: table offsets + min/max
+    void* d_levels = nullptr;      // device copy of level descriptors
+    int32_t* cand_pos = nullptr;   // [level][cand_cap]
+    float* cand_resp = nullptr;
+    int32_t* candA_pos = nullptr;  // after FAST retainBest
+    float* candA_resp = nullptr;
+    int32_t* candB_pos = nullptr;  // scratch of the Harris select
+    float* candB_resp = nullptr;
+    int32_t* kp_pos = nullptr;     // level-local pixel index of each final keypoint
+    uint16_t* pyr_tmp16 = nullptr; // row pass of the Gaussian blur
+    char rs_meta_host[1024];       // host copy of the level descriptors (LevelsDev)
+    int orb_quota_nfeatures = -1;  // nfeatures the device quotas were uploaded for
+    int32_t* counters = nullptr;   // misc device counters / histograms
+    int cand_cap = 0;
+    uint8_t* host_mask_dev = nullptr;  // explicit mask upload (scratch)
+
+    // match / pose workspace
+    uint8_t* mq = nullptr;
+    uint8_t* mt = nullptr;
+    int32_t* m_idx = nullptr;
+    int32_t* m_dist = nullptr;
+    float* pts_a = nullptr;
+    float* pts_b = nullptr;
+    uint8_t* st_a = nullptr;
+    uint8_t* st_b = nullptr;
+    float* xy_a = nullptr;
+    float* xy_b = nullptr;
+    int32_t* mq_idx = nullptr;
+    int32_t* mt_idx = nullptr;
+    double* red = nullptr;         // reduction scratch
+    uint8_t* clique_ws = nullptr;
+    size_t clique_ws_bytes = 0;
+    float* img3_ws = nullptr;
+    size_t img3_ws_bytes = 0;
+    void* pinned = nullptr;        // small pinned host buffer for readbacks
+    size_t pinned_bytes = 0;
+
+    // timing
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double t_ms[VO_T_NSTAGES] = {0};
+    int64_t t_n[VO_T_NSTAGES] = {0};
+};
+
+int vo_fail(vo_ctx* ctx, int code, const char* fmt, ...);
+
+#define VO_HIP(ctx, call)                                                               \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess)                                                          \
+            return vo_fail(ctx, VO_E_HIP, "%s failed: %s (%s:%d)", #call,              \
+                           hipGetErrorString(e__), __FILE__, __LINE__);                 \
+    } while (0)
+
+#define VO_CHECK_LAUNCH(ctx) VO_HIP(ctx, hipGetLastError())
+
+struct StageTimer {
+    vo_ctx* c;
+    int stage;
+    StageTimer(vo_ctx* ctx, int s) : c(ctx), stage(s) {
+        if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~StageTimer() {
+        if (c->timing) {
+            (void)hipEventRecord(c->ev1, c->stream);
+            (void)hipEventSynchronize(c->ev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            c->t_ms[stage] += ms;
+            c->t_n[stage] += 1;
+        }
+    }
+};
+
+static inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// implemented in the per-stage files
+int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);
+int orb_prepare_tables(vo_ctx* ctx, int w, int h);
+int orb_run(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img_stride, int w, int h,
+            int nfeatures, int mask_mode, const int16_t* d_disp16, int disp_stride, int min_d16,
+            int max_d16, const uint8_t* d_mask, int mask_stride);
+int match_knn2(vo_ctx* ctx, const uint8_t* dq, int nq, const uint8_t* dt, int nt, int32_t* d_idx,
+               int32_t* d_dist);
+int points3d_launch(vo_ctx* ctx, const int16_t* d_disp16, int w, int h, const float* d_xy, int n,
+                    float* d_xyz, uint8_t* d_status);
+void host_svd3(const double* A, double* U, double* w, double* Vt);

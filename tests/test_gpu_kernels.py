@@ -1,0 +1,128 @@
+"""GPU parity: every HIP stage, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Integer/byte/index stages must be bit-exact; float stages state their tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+from openvo_amd.synth import Corridor
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _pair(name="T0", k=3):
+    c = Corridor(name)
+    L, R = c.pair(k)
+    return c, L, R
+
+
+@pytest.mark.parametrize("cfg,mode", [("T0", 0), ("T0", 1), ("C1", 0)])
+def test_sgbm_bit_exact(oracle, ctx_small, cfg, mode):
+    c, L, R = _pair(cfg)
+    p = c.sgbm_params()
+    ctx_small.set_sgbm(p, mode)
+    got = ctx_small.sgbm_compute_host(L, R)
+    ref = oracle.sgbm_compute(L, R, p, mode)
+    assert got.shape == ref.shape
+    nbad = int((got != ref).sum())
+    assert nbad == 0, "%d of %d disparity pixels differ" % (nbad, ref.size)
+    assert (ref >= 0).mean() > 0.5  # the scene really produced disparities
+
+
+@pytest.mark.parametrize("params", [
+    dict(minDisparity=0, numDisparities=48, blockSize=5, P1=8, P2=32, disp12MaxDiff=1, preFilterCap=31,
+         uniquenessRatio=15, speckleWindowSize=0, speckleRange=0),
+    dict(minDisparity=-16, numDisparities=32, blockSize=5, P1=200, P2=800, disp12MaxDiff=2, preFilterCap=63,
+         uniquenessRatio=5, speckleWindowSize=50, speckleRange=1),
+    dict(minDisparity=4, numDisparities=16, blockSize=3, P1=24, P2=96, disp12MaxDiff=1, preFilterCap=63,
+         uniquenessRatio=10, speckleWindowSize=100, speckleRange=2),
+    dict(minDisparity=0, numDisparities=64, blockSize=9, P1=100, P2=1000, disp12MaxDiff=-1, preFilterCap=10,
+         uniquenessRatio=0, speckleWindowSize=20, speckleRange=4),
+])
+def test_sgbm_parameter_corners(oracle, ctx_small, params):
+    c, L, R = _pair("T0", 7)
+    ctx_small.set_sgbm(params, 0)
+    got = ctx_small.sgbm_compute_host(L, R)
+    ref = oracle.sgbm_compute(L, R, params, 0)
+    assert np.array_equal(got, ref)
+
+
+def test_sgbm_random_noise_images(oracle, ctx_small):
+    rng = np.random.default_rng(5)
+    L = rng.integers(0, 256, (96, 160), dtype=np.uint8)
+    R = np.roll(L, -5, axis=1)
+    p = dict(minDisparity=0, numDisparities=32, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, preFilterCap=63,
+             uniquenessRatio=10, speckleWindowSize=100, speckleRange=2)
+    ctx_small.set_sgbm(p, 0)
+    assert np.array_equal(ctx_small.sgbm_compute_host(L, R), oracle.sgbm_compute(L, R, p, 0))
+    Z = np.zeros_like(L)  # constant images: every cost ties
+    assert np.array_equal(ctx_small.sgbm_compute_host(Z, Z), oracle.sgbm_compute(Z, Z, p, 0))
+
+
+@pytest.mark.parametrize("nq,nt", [(500, 500), (1, 2), (7, 1), (3, 0), (1000, 777)])
+def test_bf_knn2_bit_exact(oracle, ctx_small, nq, nt):
+    rng = np.random.default_rng(nq * 1000 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    if nt > 10:
+        t[5] = t[3]          # forced distance ties -> lower train index first
+        q[0] = t[3]
+    gi, gd = ctx_small.bf_knn2(q, t)
+    ri, rd = oracle.bf_knn2_hamming(q, t)
+    assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
+
+
+def test_orb_matches_oracle(oracle, ctx_small):
+    c, L, R = _pair("C1", 2)
+    p = c.sgbm_params()
+    disp = oracle.sgbm_compute(L, R, p, 0)
+    d = disp.astype(np.float32) / 16
+    mask = ((d >= 4) & (d <= 100)).astype(np.uint8) * 255
+    for m in (mask, None):
+        got = ctx_small.orb_host(L, m, 500)
+        ref = oracle.orb_detect_and_compute(L, m, 500)
+        assert len(ref["xy"]) > 100
+        assert np.array_equal(got["octave"], ref["octave"])
+        assert np.array_equal(got["xy"].view(np.uint32), ref["xy"].view(np.uint32))      # keypoint indices
+        assert np.array_equal(got["response"].view(np.uint32), ref["response"].view(np.uint32))
+        assert np.array_equal(got["size"], ref["size"])
+        assert np.array_equal(got["angle"].view(np.uint32), ref["angle"].view(np.uint32))
+        assert np.array_equal(got["desc"], ref["desc"])
+
+
+def test_points3d_and_bilinear(oracle, ctx_small):
+    g = np.load(os.path.join(GOLD, "g2_bilinear.npz"))
+    out, st = ctx_small.bilinear_at(g["img"], g["xy"])
+    ref, rst = oracle.bilinear_at(g["img"], g["xy"])
+    assert np.array_equal(st, rst)
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.array_equal(out[ok].view(np.uint32), ref[ok].view(np.uint32))
+    # and against the reference's own outputs
+    good = g["kind"] == 0
+    fin = ~np.isnan(g["out"][good])
+    assert np.array_equal(out[good][fin].view(np.uint32), g["out"][good][fin].view(np.uint32))
+    assert np.array_equal(st == 2, g["kind"] == 2)
+
+
+def test_umeyama_and_rodrigues(oracle, ctx_small):
+    rng = np.random.default_rng(11)
+    src = (rng.uniform(-5, 5, (200, 3)) + [0, 0, 10]).astype(np.float32)
+    ang = 0.03
+    Rm = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    dst = (src @ Rm.T + [0.01, -0.02, -0.25] + rng.normal(scale=0.01, size=src.shape)).astype(np.float32)
+    T, s = ctx_small.umeyama(src, dst)
+    Tr, sr = oracle.umeyama(src, dst)
+    assert np.allclose(T, Tr, rtol=0, atol=1e-12) and abs(s - sr) < 1e-12
+    assert np.allclose(T[:, :3], Rm, atol=2e-3)
+    assert np.allclose(ctx_small.rodrigues(T[:, :3]), oracle.rodrigues(T[:, :3]), atol=1e-14)
+
+
+def test_rigid_clique_matches_reference_golden(ctx_small):
+    g3 = np.load(os.path.join(GOLD, "g3_rigid.npz"))
+    for k in g3.files:
+        if k.endswith("_mask"):
+            b = k[:-5]
+            m = ctx_small.rigid_clique(g3[b + "_prev"], g3[b + "_cur"], float(g3[b + "_thr"]))
+            assert np.array_equal(m, g3[k]), b
