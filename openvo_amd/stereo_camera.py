@@ -1,0 +1,117 @@
+"""StereoCamera: drop-in for openVO's class of the same name (reference stereo_camera.py:6-55).
+
+Same constructor, classmethod, attributes and methods; the per-pair work of compute_3d
+(cvtColor -> remap x2 -> StereoSGBM -> reprojectImageTo3D -> crop) runs as HIP kernels on one
+MI355X and its three return values are lazy device-backed array-likes (DeviceImage) that
+download on first numpy use, so StereoOdometer can keep the whole frame on the GPU.
+"""
+import pickle
+
+import numpy as np
+
+from . import _native, calib
+from .features import DeviceImage, FrameHandle, StereoSGBM
+
+
+class StereoCamera:
+    @classmethod
+    def from_pfiles(cls, left_cam_file, right_cam_file, rect_file, sgbm_file, img_size, **kw):
+        """Pickled dicts as the reference reads them (stereo_camera.py:8-14): cameras {'K','dist'},
+        rectification {'R','T'}, and the ten StereoSGBM keys.  pickle.load executes arbitrary code:
+        only use files you trust."""
+        loaded = []
+        for f in (left_cam_file, right_cam_file, rect_file, sgbm_file):
+            with open(f, "rb") as fh:
+                loaded.append(pickle.load(fh))
+        cam_l, cam_r, rect, sgbm = loaded
+        return cls(cam_l["K"], cam_l["dist"], cam_r["K"], cam_r["dist"], rect, sgbm, img_size, **kw)
+
+    def __init__(self, K_left, dist_left, K_right, dist_right, rect_params, sgbm_params, img_size,
+                 device=0, max_keypoints=2000, context=None):
+        """img_size = (width, height) as cv2 takes it.  Extra keyword arguments (not in the reference):
+        device = HIP device index, max_keypoints = largest nfeatures an odometer may ask for."""
+        w, h = int(img_size[0]), int(img_size[1])
+        (R1, R2, P1, P2, self.Q, self.valid_region_left,
+         self.valid_region_right) = calib.stereo_rectify(K_left, dist_left, K_right, dist_right, (w, h),
+                                                         rect_params["R"], rect_params["T"])
+        self.map_left_1, self.map_left_2 = calib.init_undistort_rectify_map(K_left, dist_left, R1, P1, (w, h))
+        self.map_right_1, self.map_right_2 = calib.init_undistort_rectify_map(K_right, dist_right, R2, P2, (w, h))
+        self.img_size = (w, h)
+        D = int(sgbm_params["numDisparities"])
+        self._ctx = context or _native.Context(device, max(w, 64), max(h, 64), max(16, ((D + 15) // 16) * 16),
+                                               int(max_keypoints))
+        self._ctx.set_rectify_maps(0, self.map_left_1, self.map_left_2)
+        self._ctx.set_rectify_maps(1, self.map_right_1, self.map_right_2)
+        self._ctx.set_Q(self.Q)
+        # crop_to_valid_region_left slices rows vr[1]:vr[3], cols vr[0]:vr[2] -- it reads the
+        # (x, y, w, h) ROI as (x0, y0, x1, y1); that behaviour is kept (stereo_camera.py:35-37)
+        vr = self.valid_region_left
+        self._ctx.set_roi(vr[0], vr[1], vr[2], vr[3])
+        self.stereoSGBM = StereoSGBM(self._ctx, sgbm_params)
+        self._slot_owner = [None] * _native.VO_NUM_SLOTS   # weak bookkeeping: FrameHandle per slot
+        self._next_slot = 0
+
+    # ---- slot bookkeeping -------------------------------------------------------------------
+    def _release_slot(self, slot, frame):
+        if self._slot_owner[slot] is not None and self._slot_owner[slot]() is frame:
+            self._slot_owner[slot] = None
+
+    def _acquire_slot(self):
+        import weakref
+        n = _native.VO_NUM_SLOTS
+        for k in range(n):
+            s = (self._next_slot + k) % n
+            ref = self._slot_owner[s]
+            if ref is None or ref() is None:
+                self._next_slot = (s + 1) % n
+                return s, weakref
+        # every slot is still referenced by user code: move the oldest frame to host memory
+        s = self._next_slot
+        old = self._slot_owner[s]()
+        if old is not None:
+            old.evict()
+        self._slot_owner[s] = None
+        self._next_slot = (s + 1) % n
+        return s, weakref
+
+    # ---- reference API ----------------------------------------------------------------------
+    def undistort_rectify_left(self, img):
+        return self._rectify(0, img)
+
+    def undistort_rectify_right(self, img):
+        return self._rectify(1, img)
+
+    def _rectify(self, cam, img):
+        img = np.asarray(img)
+        if img.ndim == 3:   # cv2.remap handles each channel alike
+            return np.stack([self._rectify(cam, img[..., c]) for c in range(img.shape[2])], -1)
+        return self._ctx.remap(cam, img, (self.img_size[1], self.img_size[0]))
+
+    def crop_to_valid_region_left(self, img):
+        vr = self.valid_region_left
+        return img[vr[1]: vr[3], vr[0]: vr[2]]
+
+    def crop_to_valid_region_right(self, img):
+        vr = self.valid_region_right
+        return img[vr[1]: vr[3], vr[0]: vr[2]]
+
+    def compute_3d(self, img_left, img_right, preprocessed=False):
+        """-> (img_3d float32 HcxWcx3, disparity float32 HcxWc, img_left uint8 HcxWc), cropped;
+        each is a DeviceImage (np.asarray(x) or x[...] materialises it)."""
+        img_left, img_right = np.asarray(img_left), np.asarray(img_right)
+        if img_left.ndim != img_right.ndim:
+            # the reference converts each image independently (stereo_camera.py:44-47)
+            if img_left.ndim == 3:
+                img_left = self._ctx.cvt_bgr2gray(img_left)
+            if img_right.ndim == 3:
+                img_right = self._ctx.cvt_bgr2gray(img_right)
+        slot, weakref = self._acquire_slot()
+        w, h = self._ctx.upload_pair(slot, img_left, img_right, preprocessed)
+        self._ctx.sgbm_compute(slot)
+        vr = self.valid_region_left
+        # numpy slice semantics (negative / oversized bounds clip)
+        y0, y1, _ = slice(vr[1], vr[3]).indices(h)
+        x0, x1, _ = slice(vr[0], vr[2]).indices(w)
+        frame = FrameHandle(self, slot, w, h, (x0, y0, max(x1, x0), max(y1, y0)))
+        self._slot_owner[slot] = weakref.ref(frame)
+        return DeviceImage(frame, "xyz"), DeviceImage(frame, "disp"), DeviceImage(frame, "left")

@@ -1,0 +1,193 @@
+"""StereoOdometer: drop-in for openVO's class (reference stereo_odometer.py:4-226).
+
+Same constructor defaults, class constants, attributes, methods, return values and
+`skip_cause` strings.  The per-frame arithmetic (disparity mask + ORB, Hamming kNN + ratio
+test, 3-D lookup, rigid-body clique filter, Umeyama fit) runs in libvo355 on the GPU; what
+stays in Python is the sequential bookkeeping of `update` -- it decides which frames pair up,
+so it follows the reference decision for decision (pinned by tests/golden/g5_state_machine.json).
+"""
+import numpy as np
+
+from .features import BFMatcher, DeviceImage, DisparityMask, KeyPointList, ORB
+
+
+class StereoOdometer:
+    # disparity range (pixels) with a usable depth estimate          [reference :6-7]
+    MIN_VALID_DISPARITY = 4
+    MAX_VALID_DISPARITY = 100
+    # per-frame motion gates, widened by (skipped_frames + 1)          [reference :10,12]
+    MAX_DISTANCE_CHANGE = 1          # metres
+    MAX_ROTATION_CHANGE = np.pi / 3  # radians
+
+    def __init__(self, stereo_camera, nfeatures=500, match_threshold=0.8, rigidity_threshold=0,
+                 outlier_threshold=0, preprocessed_frames=False, min_matches=10):
+        self.stereo = stereo_camera
+        self.current_img = self.current_disparity = self.current_3d = None
+        self.prev_img = self.prev_disparity = self.prev_3d = None
+        ctx = getattr(stereo_camera, "_ctx", None)
+        self._ctx = ctx
+        self.orb = ORB(ctx, nfeatures) if ctx is not None else None
+        self.matcher = BFMatcher(ctx) if ctx is not None else None
+        self.prev_kps = self.current_kps = None
+        self.current_desc = None
+        self.match_threshold = match_threshold
+        self.rigidity_threshold = rigidity_threshold
+        self.outlier_threshold = outlier_threshold
+        self.preprocessed_frames = preprocessed_frames
+        self.min_matches = min_matches
+        self.skipped_frames = 0      # successive frames without an accepted transform
+        self.c_T_w = np.eye(4)       # world frame expressed in the camera frame
+        self.c_T_w_prev = np.eye(4)
+        self.skip_cause = ""
+
+    # ------------------------------------------------------------------------------------------
+    def feature_mask(self, disparity):
+        """uint8 {0,255} mask of MIN_VALID_DISPARITY <= d <= MAX_VALID_DISPARITY  [reference :38-41].
+        For a device-resident disparity the mask is returned unevaluated and fused into ORB."""
+        if isinstance(disparity, DeviceImage) and disparity.kind == "disp" and disparity.frame.live:
+            return DisparityMask(disparity.frame, self.MIN_VALID_DISPARITY, self.MAX_VALID_DISPARITY)
+        d = np.asarray(disparity)
+        return ((d >= self.MIN_VALID_DISPARITY) * (d <= self.MAX_VALID_DISPARITY)).astype(np.uint8) * 255
+
+    def valid_distance_change(self, prev_kp_idx, current_kp_idx):
+        """Unused by the reference (guarded by `if (False)`, :165-166); kept for API parity [:43-48]."""
+        p_x, p_y = self.prev_kps[prev_kp_idx].pt
+        c_x, c_y = self.current_kps[current_kp_idx].pt
+        a = np.linalg.norm(np.asarray(self.prev_3d)[int(p_y)][int(p_x)])
+        b = np.linalg.norm(np.asarray(self.current_3d)[int(c_y)][int(c_x)])
+        return a - b <= self.MAX_DISTANCE_CHANGE * (self.skipped_frames + 1)
+
+    def bilinear_interpolate_pixels(self, img, x, y):
+        """Inf-aware bilinear sample of an HxWx3 image at float (x, y)  [reference :50-79].
+        Raises ZeroDivisionError when no tap is usable, like the reference."""
+        if isinstance(img, DeviceImage) and img.kind == "xyz" and img.frame.live:
+            out, st = self._ctx.points3d_at(img.frame.slot, np.array([[x, y]], np.float32))
+        else:
+            out, st = self._ctx.bilinear_at(np.asarray(img, np.float32), np.array([[x, y]], np.float32))
+        if st[0] == 2:
+            raise ZeroDivisionError("division by zero")
+        return out[0]
+
+    def rigid_body_filter(self, prev_pts, pts):
+        """Greedy maximum clique of pairwise-distance-consistent matches  [reference :82-105]."""
+        return self._ctx.rigid_clique(np.asarray(prev_pts, np.float32), np.asarray(pts, np.float32),
+                                      self.rigidity_threshold)
+
+    def save_frame_update(self, next_img, next_disp, next_3d, next_kps, next_desc):
+        self.prev_img, self.prev_disparity, self.prev_3d = self.current_img, self.current_disparity, self.current_3d
+        self.prev_kps, self.prev_desc = self.current_kps, self.current_desc
+        self.current_img, self.current_disparity, self.current_3d = next_img, next_disp, next_3d
+        self.current_kps, self.current_desc = next_kps, next_desc
+
+    # ------------------------------------------------------------------------------------------
+    def update(self, img_left, img_right):
+        """Process one stereo pair; True when the frame was accepted  [reference :115-160]."""
+        next_3d, next_disp, next_img = self.stereo.compute_3d(img_left, img_right,
+                                                              preprocessed=self.preprocessed_frames)
+        next_kps, next_desc = self.orb.detectAndCompute(next_img, self.feature_mask(next_disp))
+        if len(next_kps) < self.min_matches:
+            self.skipped_frames += 1
+            self.skip_cause = "keypoints"
+            return False
+        if self.current_img is None:           # very first usable frame
+            self.save_frame_update(next_img, next_disp, next_3d, next_kps, next_desc)
+            return True
+
+        T = self._try_pair(self.current_kps, self.current_desc, self.current_3d, next_kps, next_desc, next_3d)
+        if T is not None:
+            self.c_T_w_prev = self.c_T_w
+            self.c_T_w = T @ self.c_T_w
+        elif self.prev_img is not None:
+            # one-frame-back fallback: pair the new frame with the frame before `current`
+            T = self._try_pair(self.prev_kps, self.prev_desc, self.prev_3d, next_kps, next_desc, next_3d)
+            if T is not None:
+                base = self.c_T_w_prev
+                self.c_T_w_prev = self.c_T_w
+                self.c_T_w = T @ base
+                self.skipped_frames = 0
+        if T is None:
+            self.skipped_frames += 1          # frame is dropped, `current` stays
+            return False
+        self.skipped_frames = 0
+        self.save_frame_update(next_img, next_disp, next_3d, next_kps, next_desc)
+        return True
+
+    def _try_pair(self, kps_a, desc_a, im3d_a, kps_b, desc_b, im3d_b):
+        pts_a, pts_b = self.point_clouds(kps_a, kps_b, desc_a, desc_b, im3d_a, im3d_b)
+        if pts_a is None:
+            self.skip_cause = "matches"
+            return None
+        return self.point_cloud_transform(pts_a, pts_b)
+
+    # ------------------------------------------------------------------------------------------
+    def point_clouds(self, kps1, kps2, desc1, desc2, im3d1, im3d2):
+        """Matched 3-D points of two frames (Mx3 float32 each) or (None, None)  [reference :162-175]."""
+        fused = (type(self.matcher) is BFMatcher and self._on_device(kps1, desc1, im3d1)
+                 and self._on_device(kps2, desc2, im3d2) and len(kps2) >= 2)
+        if fused:
+            q, t, pts1, pts2, st1, st2 = self._ctx.point_clouds(kps1.frame.slot, kps2.frame.slot,
+                                                                self.match_threshold)
+            if len(q) < self.min_matches:
+                return None, None
+            if (st1 == 2).any() or (st2 == 2).any():
+                raise ZeroDivisionError("division by zero")
+            return pts1, pts2
+        # generic path: the same steps through the public seams (any matcher / arrays)
+        matches = self.matcher.knnMatch(desc1, desc2, k=2)
+        matches = [m[0] for m in matches if m[0].distance < self.match_threshold * m[1].distance]
+        if len(matches) < self.min_matches:
+            return None, None
+        pts1 = [self.bilinear_interpolate_pixels(im3d1, *kps1[m.queryIdx].pt) for m in matches]
+        pts2 = [self.bilinear_interpolate_pixels(im3d2, *kps2[m.trainIdx].pt) for m in matches]
+        return np.array(pts1), np.array(pts2)
+
+    @staticmethod
+    def _on_device(kps, desc, im3d):
+        return (isinstance(kps, KeyPointList) and kps.frame is not None and kps.frame.live
+                and desc is kps.desc and isinstance(im3d, DeviceImage) and im3d.frame is kps.frame)
+
+    def _estimate(self, src, dst):
+        """cv2.estimateAffine3D(src, dst, force_rotation=True)[0] with the homogeneous row appended."""
+        T34, _ = self._ctx.umeyama(src, dst, True)
+        return np.vstack([T34, [0, 0, 0, 1]])
+
+    def point_cloud_transform(self, current_pts, next_pts):
+        """Rigid transform current -> next (4x4) or None with skip_cause set  [reference :177-223]."""
+        if self.rigidity_threshold > 0:
+            keep = self.rigid_body_filter(current_pts, next_pts) > 0
+            current_pts, next_pts = current_pts[keep], next_pts[keep]
+        too_few_rigid = len(current_pts) < 10
+        if too_few_rigid:
+            self.skip_cause = "rigidity"
+        if self.outlier_threshold > 0 and not too_few_rigid:
+            # single-pass outlier rejection on the relative residual of a first fit  [:188-197]
+            T = self._estimate(current_pts, next_pts)
+            h_next = np.hstack([next_pts, np.ones((len(next_pts), 1))]).astype(np.float64)
+            h_cur = np.hstack([current_pts, np.ones((len(current_pts), 1))]).astype(np.float64)
+            errors = np.linalg.norm(h_next - h_cur @ T.T, axis=1) / np.linalg.norm(h_next, axis=1)
+            keep = errors < self.outlier_threshold + np.median(errors)
+            current_pts, next_pts = current_pts[keep], next_pts[keep]
+        if len(current_pts) < self.min_matches:
+            if not too_few_rigid:
+                self.skip_cause = "outlier"
+            return None
+        T = self._estimate(current_pts, next_pts)
+        if np.isnan(T).any():
+            self.skip_cause = "nan"
+            return None
+        scale = self.skipped_frames + 1
+        dist = np.linalg.norm(T[0:3, 3])
+        angle = np.linalg.norm(self._ctx.rodrigues(T[0:3, 0:3]))
+        too_far = dist > self.MAX_DISTANCE_CHANGE * scale
+        too_turned = angle > self.MAX_ROTATION_CHANGE * scale
+        if too_far:
+            self.skip_cause = "bigdist"
+        if too_turned:
+            self.skip_cause = "bigrot"
+        if too_far or too_turned:
+            return None
+        return T
+
+    def current_pose(self):
+        """Camera pose in world (= first accepted frame) coordinates  [reference :225-226]."""
+        return np.linalg.inv(self.c_T_w)

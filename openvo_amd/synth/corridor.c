@@ -2,7 +2,9 @@
  * Deterministic synthetic "corridor" stereo sequence:
  * analytic per-pixel ray cast of an ideal rectified rig (zero distortion, R = I,
  * T = (-B, 0, 0)) through ground plane y = +1.65 m, side walls x = +-half_width and a
- * back wall z_far ahead of the current camera; world-anchored 3-octave value-noise
+ * back wall FIXED in the world at z = z_far (SURVEY 8(d) proposed a wall moving with the
+ * camera; its features contradict the camera motion and wreck the reference's outlier-free
+ * Umeyama fit, so the wall is world-anchored and far instead); world-anchored 3-octave value-noise
  * texture from an integer lattice hash (seed 1234).  Bench/test input generator --
  * not part of the reference and not part of the oracle.
  */
@@ -64,7 +66,7 @@ static void render(const vo_corridor_cfg* c, double px, double pz, double yaw, d
             if (wy > 1e-12) { double t = c->ground_y / wy; if (t < tbest) { tbest = t; plane = 0; } }
             if (wx < -1e-12) { double t = (-c->half_width - ex) / wx; if (t > 0 && t < tbest) { tbest = t; plane = 1; } }
             if (wx > 1e-12) { double t = (c->half_width - ex) / wx; if (t > 0 && t < tbest) { tbest = t; plane = 2; } }
-            if (wz > 1e-12) { double t = (pz + c->z_far - ez) / wz; if (t > 0 && t < tbest) { tbest = t; plane = 3; } }
+            if (wz > 1e-12) { double t = (c->z_far - ez) / wz; if (t > 0 && t < tbest) { tbest = t; plane = 3; } }
             double X = ex + tbest * wx, Y = tbest * wy, Z = ez + tbest * wz;
             uint8_t g;
             if (plane == 0) g = shade(X, Z, 0, c->seed);

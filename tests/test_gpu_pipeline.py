@@ -1,0 +1,148 @@
+"""End-to-end GPU parity: StereoCamera / StereoOdometer (HIP behind the C ABI) against the CPU
+oracle pipeline on the same synthetic sequences, plus size-independent properties at the full
+BASELINE sizes."""
+import numpy as np
+import pytest
+
+from openvo_amd import StereoCamera, StereoOdometer
+from openvo_amd.synth import Corridor
+
+pytestmark = pytest.mark.gpu
+
+
+def _rig(name, **kw):
+    c = Corridor(name)
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), **kw)
+    return c, cam
+
+
+def _ref(c, cam, **kw):
+    from oracle.odometer import RefStereoCamera, RefStereoOdometer
+    rcam = RefStereoCamera(cam.Q, cam.valid_region_left, c.sgbm_params())
+    return rcam, RefStereoOdometer(rcam, **kw)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(rigidity_threshold=0.1, outlier_threshold=0.02)])
+def test_c1_sequence_matches_oracle(kw):
+    """BASELINE config 1: 10 synthetic 640x480 pairs.  Every frame: accept flag, skip_cause,
+    disparity, keypoint set, descriptors identical; chained pose within 1e-9 (float64 sums are
+    reduced in a different order on the GPU)."""
+    c, cam = _rig("C1", max_keypoints=500)
+    odo = StereoOdometer(cam, preprocessed_frames=True, **kw)
+    rcam, rodo = _ref(c, cam, preprocessed_frames=True, **kw)
+    vr = cam.valid_region_left
+    for k in range(10):
+        L, R = c.pair(k)
+        a, b = odo.update(L, R), rodo.update(L, R)
+        assert a == b and odo.skip_cause == rodo.skip_cause and odo.skipped_frames == rodo.skipped_frames, k
+        if a:
+            d16 = np.rint(np.asarray(odo.current_disparity) * 16).astype(np.int16)
+            assert np.array_equal(d16, rcam.last_disp16[vr[1]:vr[3], vr[0]:vr[2]])
+            assert np.array_equal(odo.current_kps.xy.view(np.uint32), rodo.cur["kps"]["xy"].view(np.uint32))
+            assert np.array_equal(odo.current_kps.octave, rodo.cur["kps"]["octave"])
+            assert np.array_equal(odo.current_desc, rodo.cur["desc"])
+        assert np.allclose(odo.c_T_w, rodo.c_T_w, rtol=0, atol=1e-9), k
+    ate = np.sqrt(np.mean([np.sum((odo.current_pose()[:3, 3] - rodo.current_pose()[:3, 3]) ** 2)]))
+    assert ate <= 1e-4
+
+
+def test_compute_3d_outputs_and_cv2_seams(oracle):
+    """compute_3d's three lazily materialised return values and each cv2-object seam."""
+    c, cam = _rig("T0", max_keypoints=500)
+    L, R = c.pair(2)
+    img_3d, disp, left = cam.compute_3d(L, R, preprocessed=True)
+    vr = cam.valid_region_left
+    ref16 = oracle.sgbm_compute(L, R, c.sgbm_params(), 0)
+    refd = (ref16.astype(np.float32) / 16)
+    assert disp.shape == refd[vr[1]:vr[3], vr[0]:vr[2]].shape and disp.dtype == np.float32
+    assert np.array_equal(np.asarray(disp), refd[vr[1]:vr[3], vr[0]:vr[2]])
+    assert np.array_equal(np.asarray(left), L[vr[1]:vr[3], vr[0]:vr[2]])
+    with np.errstate(all="ignore"):
+        ref3 = oracle.reproject_to_3d(refd, cam.Q)[vr[1]:vr[3], vr[0]:vr[2]]
+    got3 = np.asarray(img_3d)
+    assert got3.shape == ref3.shape and got3.dtype == np.float32
+    assert np.array_equal(got3.view(np.uint32), ref3.view(np.uint32))       # incl. inf / nan patterns
+    # stereoSGBM.compute seam
+    assert np.array_equal(cam.stereoSGBM.compute(L, R), ref16)
+    # orb.detectAndCompute / matcher.knnMatch seams on plain numpy arrays
+    odo = StereoOdometer(cam, nfeatures=300)
+    mask = odo.feature_mask(np.asarray(disp))
+    kps, desc = odo.orb.detectAndCompute(np.asarray(left), mask)
+    ref = oracle.orb_detect_and_compute(np.asarray(left), mask, 300)
+    assert np.array_equal(desc, ref["desc"]) and np.array_equal(kps.xy, ref["xy"])
+    assert isinstance(kps[0].pt, tuple) and isinstance(kps[0].pt[0], float)
+    # the fused device path gives the same keypoints as the host-array path
+    kps2, desc2 = odo.orb.detectAndCompute(left, odo.feature_mask(disp))
+    assert np.array_equal(desc2, desc) and np.array_equal(kps2.xy, kps.xy)
+    m = odo.matcher.knnMatch(desc, desc[::-1].copy(), k=2)
+    ri, rd = oracle.bf_knn2_hamming(desc, desc[::-1].copy())
+    assert [x[0].trainIdx for x in m] == ri[:, 0].tolist() and [x[1].distance for x in m] == rd[:, 1].astype(float).tolist()
+    # bilinear_interpolate_pixels seam: device image and host array agree with the oracle
+    xy = kps.xy[:20]
+    refp, _ = oracle.bilinear_at(ref3, xy)
+    for i in range(len(xy)):
+        p = odo.bilinear_interpolate_pixels(img_3d, float(xy[i, 0]), float(xy[i, 1]))
+        q = odo.bilinear_interpolate_pixels(got3, float(xy[i, 0]), float(xy[i, 1]))
+        assert np.array_equal(p, refp[i]) and np.array_equal(q, refp[i])
+
+
+def test_unrectified_colour_input(oracle):
+    """cvtColor + remap front-end (preprocessed=False, BGR input) against the oracle."""
+    from openvo_amd import calib
+    c = Corridor("T0")
+    dist = np.array([-0.08, 0.01, 0.0005, -0.0003, 0.0])
+    rect = {"R": calib.rodrigues_vec_to_mat([0.002, 0.004, -0.003]), "T": np.array([-c.B, 0.001, 0.0])}
+    cam = StereoCamera(c.K(), dist, c.K(), dist, rect, c.sgbm_params(), (c.w, c.h), max_keypoints=300)
+    L, R = c.pair(1)
+    Lc = np.stack([L, np.roll(L, 1, 0), 255 - L], -1)
+    Rc = np.stack([R, np.roll(R, 1, 0), 255 - R], -1)
+    _, disp, left = cam.compute_3d(Lc, Rc)
+    gl = oracle.remap_bilinear(oracle.bgr2gray(Lc), cam.map_left_1, cam.map_left_2)
+    gr = oracle.remap_bilinear(oracle.bgr2gray(Rc), cam.map_right_1, cam.map_right_2)
+    vr = cam.valid_region_left
+    assert np.array_equal(np.asarray(left), gl[vr[1]:vr[3], vr[0]:vr[2]])
+    assert np.array_equal(cam.undistort_rectify_right(oracle.bgr2gray(Rc)), gr)
+    ref16 = oracle.sgbm_compute(gl, gr, c.sgbm_params(), 0)
+    assert np.array_equal(np.rint(np.asarray(disp) * 16).astype(np.int16), ref16[vr[1]:vr[3], vr[0]:vr[2]])
+
+
+def test_frame_eviction_keeps_results():
+    """Holding more frames than device slots moves the oldest to host memory transparently."""
+    c, cam = _rig("T0", max_keypoints=300)
+    outs = []
+    for k in range(6):
+        L, R = c.pair(k)
+        outs.append(cam.compute_3d(L, R, preprocessed=True))
+    first = np.asarray(outs[0][1])
+    fresh = np.asarray(cam.compute_3d(*c.pair(0), preprocessed=True)[1])
+    assert np.array_equal(first, fresh)
+
+
+@pytest.mark.parametrize("name,mode,nfeat", [("C2", 0, 500), ("C4", 1, 500)])
+def test_full_size_properties(name, mode, nfeat):
+    """BASELINE full sizes (1280x720 D=128 5-path; 2048x1536 D=256 8-path): properties that do
+    not need the (slow) oracle -- determinism, left band invalid, ground-plane disparity law,
+    disparity range of valid pixels, keypoints respect the mask, match self-consistency."""
+    c = Corridor(name)
+    p = c.sgbm_params(mode)
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), p, (c.w, c.h), max_keypoints=nfeat)
+    L, R = c.pair(5)
+    d1 = cam.stereoSGBM.compute(L, R)
+    d2 = cam.stereoSGBM.compute(L, R)
+    assert np.array_equal(d1, d2)                                   # idempotent / deterministic
+    assert (d1[:, : c.D] == -16).all()                              # columns < numDisparities are INVALID
+    valid = d1 >= 0
+    assert valid.mean() > 0.5 and d1[valid].max() < c.D * 16
+    v = int(c.cy + 0.3 * c.h)
+    row = d1[v][d1[v] > 0] / 16.0
+    assert abs(np.median(row) - c.B * (v - c.cy) / 1.65) < 0.5      # ground plane: d = B (v - cy) / 1.65
+    odo = StereoOdometer(cam, nfeatures=nfeat, preprocessed_frames=True)
+    assert odo.update(L, R)
+    kps = odo.current_kps
+    assert 0.8 * nfeat <= len(kps) <= nfeat + 64
+    dd = np.asarray(odo.current_disparity)
+    lvl0 = kps.octave == 0
+    xy = kps.xy[lvl0].astype(int)
+    assert ((dd[xy[:, 1], xy[:, 0]] >= 4) & (dd[xy[:, 1], xy[:, 0]] <= 100)).all()   # mask respected
+    idx, dist = cam._ctx.bf_knn2(odo.current_desc, odo.current_desc)
+    assert (idx[:, 0] == np.arange(len(kps))).all() and (dist[:, 0] == 0).all()       # self-match
