@@ -63,6 +63,11 @@ int vo_set_roi(vo_ctx* ctx, int x0, int y0, int x1, int y1);
  * Leaves rectified gray left/right on the device in `slot`. */
 int vo_upload_pair(vo_ctx* ctx, int slot, const uint8_t* left, const uint8_t* right, int w, int h,
                    int channels, int preprocessed);
+/* streaming ingest: keep n input pairs resident in HBM (vo_stage_pairs_alloc + vo_stage_pair),
+ * then feed a slot from pair `index` without touching the host (same processing as vo_upload_pair) */
+int vo_stage_pairs_alloc(vo_ctx* ctx, int n, int w, int h, int channels);
+int vo_stage_pair(vo_ctx* ctx, int index, const uint8_t* left, const uint8_t* right);
+int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
 /* self.stereoSGBM.compute(L, R) [:51]: int16 disparity x16 of the slot's pair; kept on the
  * device; disp16_out (h*w) may be NULL */
 int vo_sgbm_compute(vo_ctx* ctx, int slot, int16_t* disp16_out);
@@ -134,9 +139,11 @@ int vo_rigid_clique(vo_ctx* ctx, const float* prev, const float* cur, int m, dou
 int vo_rodrigues(const double* R9, double* r3);
 
 /* instrumentation ------------------------------------------------------------------------ */
-/* hipEvent timing of the kernels launched on the context stream.  Stage ids: */
+/* hipEvent timing of the kernels launched on the context stream (events are recorded without
+ * blocking and resolved by vo_get_timings).  Stage ids: */
 enum { VO_T_UPLOAD = 0, VO_T_SGBM_COST, VO_T_SGBM_AGG, VO_T_SGBM_WTA, VO_T_SGBM_POST, VO_T_ORB,
        VO_T_MATCH, VO_T_POSE, VO_T_NSTAGES };
+/* on = 0 off, 1 every stage, otherwise (stage bit mask << 1), e.g. (1 << VO_T_SGBM_AGG) << 1 */
 int vo_enable_timing(vo_ctx* ctx, int on);
 /* accumulated milliseconds and launch counts per stage since the last reset */
 int vo_get_timings(vo_ctx* ctx, double* ms_out /*VO_T_NSTAGES*/, int64_t* launches_out, int reset);

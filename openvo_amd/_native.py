@@ -20,6 +20,7 @@ T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "
 SYMBOLS = [
     "vo_create", "vo_destroy", "vo_last_error", "vo_device_name", "vo_synchronize",
     "vo_set_rectify_maps", "vo_set_sgbm", "vo_set_Q", "vo_set_roi", "vo_upload_pair",
+    "vo_stage_pairs_alloc", "vo_stage_pair", "vo_load_staged_pair",
     "vo_sgbm_compute", "vo_sgbm_compute_host", "vo_download_disparity_f32", "vo_download_xyz",
     "vo_download_left", "vo_download_right", "vo_cvt_bgr2gray", "vo_remap", "vo_reproject_to_3d",
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints",
@@ -73,6 +74,9 @@ def lib():
         L.vo_set_Q.argtypes = [vp, vp]
         L.vo_set_roi.argtypes = [vp, ci, ci, ci, ci]
         L.vo_upload_pair.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci]
+        L.vo_stage_pairs_alloc.argtypes = [vp, ci, ci, ci, ci]
+        L.vo_stage_pair.argtypes = [vp, ci, vp, vp]
+        L.vo_load_staged_pair.argtypes = [vp, ci, ci, ci]
         L.vo_sgbm_compute.argtypes = [vp, ci, vp]
         L.vo_sgbm_compute_host.argtypes = [vp, vp, vp, ci, ci, vp]
         for f in (L.vo_download_disparity_f32, L.vo_download_xyz, L.vo_download_left, L.vo_download_right):
@@ -169,6 +173,23 @@ class Context:
         h, w = left.shape[:2]
         self._ck(self._lib.vo_upload_pair(self._h, slot, _p(left), _p(right), w, h, ch, int(bool(preprocessed))))
         return w, h
+
+    def stage_pairs(self, pairs):
+        """Upload a list of (left, right) host pairs once; they stay resident in HBM."""
+        l0 = np.asarray(pairs[0][0])
+        ch = 3 if l0.ndim == 3 else 1
+        h, w = l0.shape[:2]
+        self._ck(self._lib.vo_stage_pairs_alloc(self._h, len(pairs), w, h, ch))
+        for i, (l, r) in enumerate(pairs):
+            l, r = _c(l, np.uint8), _c(r, np.uint8)
+            if l.shape != l0.shape or r.shape != l0.shape:
+                raise ValueError("all staged pairs must share one shape")
+            self._ck(self._lib.vo_stage_pair(self._h, i, _p(l), _p(r)))
+        self.staged_shape = (w, h)
+
+    def load_staged_pair(self, slot, index, preprocessed):
+        self._ck(self._lib.vo_load_staged_pair(self._h, slot, int(index), int(bool(preprocessed))))
+        return self.staged_shape
 
     def sgbm_compute(self, slot, shape=None):
         out = np.empty(shape, np.int16) if shape is not None else None
@@ -328,8 +349,12 @@ class Context:
         return r.reshape(3, 1)
 
     # ---- instrumentation
-    def enable_timing(self, on=True):
-        self._ck(self._lib.vo_enable_timing(self._h, int(on)))
+    def enable_timing(self, on=True, stages=None):
+        """stages: iterable of stage names (T_STAGES) to restrict the event timing to."""
+        flag = int(bool(on))
+        if on and stages is not None:
+            flag = sum(1 << T_STAGES.index(s) for s in stages) << 1
+        self._ck(self._lib.vo_enable_timing(self._h, flag))
 
     def timings(self, reset=False):
         ms = np.zeros(len(T_STAGES), np.float64)

@@ -156,13 +156,14 @@ extern "C" int vo_points3d_at(vo_ctx* ctx, int slot, const float* xy, int n, flo
     for (int i = 0; i < n; i++)
         if (!(xy[2 * i] >= 0 && xy[2 * i + 1] >= 0 && (int)xy[2 * i] < cw && (int)xy[2 * i + 1] < chh))
             return vo_fail(ctx, VO_E_ARG, "keypoint %d (%g,%g) outside the %dx%d cropped image", i, xy[2 * i], xy[2 * i + 1], cw, chh);
-    VO_HIP(ctx, hipMemcpyAsync(ctx->xy_a, xy, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    int rc = points3d_launch(ctx, f.disp16, f.w, f.h, ctx->xy_a, n, ctx->pts_a, ctx->st_a);
+    int rc = xfer_h2d(ctx, ctx->xy_a, xy, (size_t)n * 8);
     if (rc) return rc;
-    VO_HIP(ctx, hipMemcpyAsync(xyz_out, ctx->pts_a, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipMemcpyAsync(status_out, ctx->st_a, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return VO_OK;
+    rc = points3d_launch(ctx, f.disp16, f.w, f.h, ctx->xy_a, n, ctx->pts_a, ctx->st_a);
+    if (rc) return rc;
+    rc = xfer_d2h(ctx, xyz_out, ctx->pts_a, (size_t)n * 12);
+    if (!rc) rc = xfer_d2h(ctx, status_out, ctx->st_a, (size_t)n);
+    if (rc) return rc;
+    return xfer_flush(ctx);
 }
 
 static int ensure_ws(vo_ctx* ctx, float** p, size_t* have, size_t bytes)
@@ -188,14 +189,15 @@ extern "C" int vo_bilinear_at(vo_ctx* ctx, const float* img3d, int w, int h, con
     int rc = ensure_ws(ctx, &ctx->img3_ws, &ctx->img3_ws_bytes, (size_t)w * h * 12);
     if (rc) return rc;
     VO_HIP(ctx, hipMemcpyAsync(ctx->img3_ws, img3d, (size_t)w * h * 12, hipMemcpyHostToDevice, ctx->stream));
-    VO_HIP(ctx, hipMemcpyAsync(ctx->xy_a, xy, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = xfer_h2d(ctx, ctx->xy_a, xy, (size_t)n * 8);
+    if (rc) return rc;
     TapImg tap{ ctx->img3_ws, w };
     hipLaunchKernelGGL(k_bilinear_img, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, tap, w, h, ctx->xy_a, n, ctx->pts_a, ctx->st_a);
     VO_CHECK_LAUNCH(ctx);
-    VO_HIP(ctx, hipMemcpyAsync(out, ctx->pts_a, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipMemcpyAsync(status_out, ctx->st_a, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return VO_OK;
+    rc = xfer_d2h(ctx, out, ctx->pts_a, (size_t)n * 12);
+    if (!rc) rc = xfer_d2h(ctx, status_out, ctx->st_a, (size_t)n);
+    if (rc) return rc;
+    return xfer_flush(ctx);
 }
 
 extern "C" int vo_reproject_to_3d(vo_ctx* ctx, const float* disp, int w, int h, const double* Q16, float* xyz)
@@ -312,14 +314,15 @@ extern "C" int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio
     }
     if (m > cap && (q_idx || t_idx || pts_a || pts_b || status_a || status_b))
         return vo_fail(ctx, VO_E_CAP, "%d matches exceed output capacity %d", m, cap);
-    if (q_idx) VO_HIP(ctx, hipMemcpyAsync(q_idx, ctx->mq_idx, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (t_idx) VO_HIP(ctx, hipMemcpyAsync(t_idx, ctx->mt_idx, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (pts_a) VO_HIP(ctx, hipMemcpyAsync(pts_a, ctx->pts_a, (size_t)m * 12, hipMemcpyDeviceToHost, ctx->stream));
-    if (pts_b) VO_HIP(ctx, hipMemcpyAsync(pts_b, ctx->pts_b, (size_t)m * 12, hipMemcpyDeviceToHost, ctx->stream));
-    if (status_a) VO_HIP(ctx, hipMemcpyAsync(status_a, ctx->st_a, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
-    if (status_b) VO_HIP(ctx, hipMemcpyAsync(status_b, ctx->st_b, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return VO_OK;
+    rc = VO_OK;
+    if (q_idx && !rc) rc = xfer_d2h(ctx, q_idx, ctx->mq_idx, (size_t)m * 4);
+    if (t_idx && !rc) rc = xfer_d2h(ctx, t_idx, ctx->mt_idx, (size_t)m * 4);
+    if (pts_a && !rc) rc = xfer_d2h(ctx, pts_a, ctx->pts_a, (size_t)m * 12);
+    if (pts_b && !rc) rc = xfer_d2h(ctx, pts_b, ctx->pts_b, (size_t)m * 12);
+    if (status_a && !rc) rc = xfer_d2h(ctx, status_a, ctx->st_a, (size_t)m);
+    if (status_b && !rc) rc = xfer_d2h(ctx, status_b, ctx->st_b, (size_t)m);
+    if (rc) return rc;
+    return xfer_flush(ctx);
 }
 
 // ---- Umeyama: two-pass float64 reductions on the device, 3x3 SVD on the host -------------
@@ -485,13 +488,14 @@ extern "C" int vo_umeyama(vo_ctx* ctx, const float* src, const float* dst, int m
     if (m > ctx->kp_cap) return vo_fail(ctx, VO_E_CAP, "m=%d exceeds capacity %d", m, ctx->kp_cap);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     StageTimer t(ctx, VO_T_POSE);
-    VO_HIP(ctx, hipMemcpyAsync(ctx->pts_a, src, (size_t)m * 12, hipMemcpyHostToDevice, ctx->stream));
-    VO_HIP(ctx, hipMemcpyAsync(ctx->pts_b, dst, (size_t)m * 12, hipMemcpyHostToDevice, ctx->stream));
+    int rc = xfer_h2d(ctx, ctx->pts_a, src, (size_t)m * 12);
+    if (!rc) rc = xfer_h2d(ctx, ctx->pts_b, dst, (size_t)m * 12);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_umeyama_sums, dim3(1), dim3(256), 0, ctx->stream, ctx->pts_a, ctx->pts_b, m, ctx->red);
     hipLaunchKernelGGL(k_umeyama_cov, dim3(1), dim3(256), 0, ctx->stream, ctx->pts_a, ctx->pts_b, m, ctx->red);
     VO_CHECK_LAUNCH(ctx);
     VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->red, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = xfer_flush(ctx))) return rc;
     return umeyama_finish(ctx, (const double*)ctx->pinned, m, force_rotation, T12, scale_out);
 }
 
@@ -544,86 +548,66 @@ __global__ void k_rigid_cons(const float* __restrict__ prev, const float* __rest
     if (c) atomicAdd(&ncons[j], 1);  // column sums
 }
 
-__global__ void __launch_bounds__(1024) k_rigid_clique(const uint8_t* __restrict__ cons, const int* __restrict__ ncons, int m,
-                                                       int* __restrict__ clique, int* __restrict__ compat,
-                                                       long long* __restrict__ mask_out)
+// greedy clique on ONE wave (no block barriers): lanes stride over the m candidates; the
+// compatibility test (cons[i,:] . clique >= |clique|) is kept incrementally -- adding `sel` to the
+// clique adds column `sel` of the consistency matrix to the running dot products.
+__global__ void __launch_bounds__(64) k_rigid_clique(const uint8_t* __restrict__ cons, const int* __restrict__ ncons, int m,
+                                                     long long* __restrict__ mask_out)
 {
-    __shared__ long long s_key[16];
-    __shared__ int s_sel, s_sum, s_stop;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
-    // block-wide argmax with first-max tie rule: key = value << 32 | (0x7fffffff - index), max
-    auto block_argmax = [&](long long key) -> int {
-        for (int o = 32; o > 0; o >>= 1) { long long other = __shfl_down(key, o, 64); key = other > key ? other : key; }
-        if (lane == 0) s_key[wv] = key;
-        __syncthreads();
-        if (tid == 0) {
-            long long k = s_key[0];
-            for (int q = 1; q < nw; q++) k = s_key[q] > k ? s_key[q] : k;
-            s_sel = 0x7fffffff - (int)(k & 0x7fffffffLL);
-        }
-        __syncthreads();
-        return s_sel;
+    extern __shared__ int s_mem[];
+    int* clique = s_mem;
+    int* compat = s_mem + m;
+    int* dots = s_mem + 2 * m;
+    const int lane = threadIdx.x;
+    // wave argmax with numpy's first-max tie rule: key = value << 32 | (0x7fffffff - index)
+    auto wave_argmax = [&](long long key) -> int {
+        for (int o = 32; o > 0; o >>= 1) { long long other = __shfl_xor(key, o, 64); key = other > key ? other : key; }
+        return 0x7fffffff - (int)(key & 0x7fffffffLL);
     };
-    // seed = argmax(num_consistent)
     long long key = -0x7fffffffffffffffLL;
-    for (int j = tid; j < m; j += nt) {
+    for (int j = lane; j < m; j += 64) {
         long long k = ((long long)ncons[j] << 32) | (long long)(0x7fffffff - j);
         key = k > key ? k : key;
     }
-    const int seed = block_argmax(key);
-    for (int j = tid; j < m; j += nt) { clique[j] = j == seed; compat[j] = cons[(size_t)seed * m + j]; }
-    __syncthreads();
+    const int seed = wave_argmax(key);          // argmax(num_consistent)
+    for (int j = lane; j < m; j += 64) {
+        clique[j] = j == seed;
+        compat[j] = cons[(size_t)seed * m + j];
+        dots[j] = cons[(size_t)seed * m + j];   // the matrix is symmetric: read rows (coalesced), not columns
+    }
+    int csize = 1;
     for (int it = 0; it < m; it++) {
-        // candidates = compatible - clique; stop when sum == 0; selected = argmax(ncons*cand)
+        // candidates = compatible - clique; stop when they sum to 0; selected = argmax(ncons * cand)
         int psum = 0;
         key = -0x7fffffffffffffffLL;
-        for (int j = tid; j < m; j += nt) {
-            int cand = compat[j] - clique[j];
+        for (int j = lane; j < m; j += 64) {
+            const int cand = compat[j] - clique[j];
             psum += cand;
-            long long v = (long long)ncons[j] * cand;
-            long long k = (v << 32) | (long long)(0x7fffffff - j);
+            const long long v = (long long)ncons[j] * cand;
+            const long long k = (v << 32) | (long long)(0x7fffffff - j);
             key = k > key ? k : key;
         }
-        if (tid == 0) s_sum = 0;
-        __syncthreads();
-        for (int o = 32; o > 0; o >>= 1) psum += __shfl_down(psum, o, 64);
-        if (lane == 0 && psum) atomicAdd(&s_sum, psum);
-        __syncthreads();
-        if (tid == 0) s_stop = (s_sum == 0);
-        __syncthreads();
-        if (s_stop) break;
-        const int sel = block_argmax(key);
-        if (tid == 0) clique[sel] = 1;
-        __syncthreads();
-        // csize = sum(clique)
-        int cs = 0;
-        for (int j = tid; j < m; j += nt) cs += clique[j];
-        if (tid == 0) s_sum = 0;
-        __syncthreads();
-        for (int o = 32; o > 0; o >>= 1) cs += __shfl_down(cs, o, 64);
-        if (lane == 0 && cs) atomicAdd(&s_sum, cs);
-        __syncthreads();
-        const int csize = s_sum;
-        __syncthreads();
-        // compatible[i] = (cons[i,:] . clique) >= csize   (one wave per row i)
-        for (int i = wv; i < m; i += nw) {
-            int dot = 0;
-            for (int j = lane; j < m; j += 64) dot += cons[(size_t)i * m + j] & clique[j];
-            for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
-            if (lane == 0) compat[i] = dot >= csize;
+        for (int o = 32; o > 0; o >>= 1) psum += __shfl_xor(psum, o, 64);
+        if (psum == 0) break;
+        const int sel = wave_argmax(key);
+        const bool fresh = clique[sel] == 0;   // wave-uniform read
+        __builtin_amdgcn_wave_barrier();
+        if (fresh) {
+            csize++;
+            for (int j = lane; j < m; j += 64) dots[j] += cons[(size_t)sel * m + j];
+            if (lane == 0) clique[sel] = 1;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < m; j += 64) compat[j] = dots[j] >= csize;
     }
-    __syncthreads();
-    for (int j = tid; j < m; j += nt) mask_out[j] = clique[j];
+    for (int j = lane; j < m; j += 64) mask_out[j] = clique[j];
 }
 
 extern "C" int vo_rigid_clique(vo_ctx* ctx, const float* prev, const float* cur, int m, double thr, int64_t* mask_out)
 {
     if (!ctx || !prev || !cur || !mask_out || m < 0) return vo_fail(ctx, VO_E_ARG, "vo_rigid_clique: bad argument");
     if (m == 0) return VO_OK;
-    if (m > ctx->kp_cap) return vo_fail(ctx, VO_E_CAP, "m=%d exceeds capacity %d", m, ctx->kp_cap);
+    if (m > ctx->kp_cap || (size_t)m * 12 > 150 * 1024) return vo_fail(ctx, VO_E_CAP, "m=%d exceeds capacity", m);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     const size_t need = (size_t)m * m + (size_t)m * 4 * 3 + (size_t)m * 8 + 1024;
     if (ctx->clique_ws_bytes < need) {
@@ -639,13 +623,13 @@ extern "C" int vo_rigid_clique(vo_ctx* ctx, const float* prev, const float* cur,
     int* d_clique = d_ncons + m;
     int* d_compat = d_clique + m;
     uint8_t* d_cons = (uint8_t*)(d_compat + m);
-    VO_HIP(ctx, hipMemcpyAsync(ctx->pts_a, prev, (size_t)m * 12, hipMemcpyHostToDevice, ctx->stream));
-    VO_HIP(ctx, hipMemcpyAsync(ctx->pts_b, cur, (size_t)m * 12, hipMemcpyHostToDevice, ctx->stream));
+    int rc = xfer_h2d(ctx, ctx->pts_a, prev, (size_t)m * 12);
+    if (!rc) rc = xfer_h2d(ctx, ctx->pts_b, cur, (size_t)m * 12);
+    if (rc) return rc;
     VO_HIP(ctx, hipMemsetAsync(d_ncons, 0, (size_t)m * 4, ctx->stream));
     hipLaunchKernelGGL(k_rigid_cons, dim3(div_up(m, 256), m), dim3(256), 0, ctx->stream, ctx->pts_a, ctx->pts_b, m, (float)thr, d_cons, d_ncons);
-    hipLaunchKernelGGL(k_rigid_clique, dim3(1), dim3(1024), 0, ctx->stream, d_cons, d_ncons, m, d_clique, d_compat, d_mask);
+    hipLaunchKernelGGL(k_rigid_clique, dim3(1), dim3(64), (size_t)m * 12, ctx->stream, d_cons, d_ncons, m, d_mask);
     VO_CHECK_LAUNCH(ctx);
-    VO_HIP(ctx, hipMemcpyAsync(mask_out, d_mask, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return VO_OK;
+    if ((rc = xfer_d2h(ctx, mask_out, d_mask, (size_t)m * 8))) return rc;
+    return xfer_flush(ctx);
 }

@@ -69,12 +69,13 @@ extern "C" int vo_bf_knn2_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const u
     if (nq == 0) return VO_OK;
     VO_HIP(ctx, hipSetDevice(ctx->device));
     StageTimer tm(ctx, VO_T_MATCH);
-    VO_HIP(ctx, hipMemcpyAsync(ctx->mq, q, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (nt) VO_HIP(ctx, hipMemcpyAsync(ctx->mt, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
-    int rc = match_knn2(ctx, ctx->mq, nq, ctx->mt, nt, ctx->m_idx, ctx->m_dist);
+    int rc = xfer_h2d(ctx, ctx->mq, q, (size_t)nq * 32);
+    if (!rc && nt) rc = xfer_h2d(ctx, ctx->mt, t, (size_t)nt * 32);
     if (rc) return rc;
-    VO_HIP(ctx, hipMemcpyAsync(idx, ctx->m_idx, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipMemcpyAsync(dist, ctx->m_dist, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return VO_OK;
+    rc = match_knn2(ctx, ctx->mq, nq, ctx->mt, nt, ctx->m_idx, ctx->m_dist);
+    if (rc) return rc;
+    rc = xfer_d2h(ctx, idx, ctx->m_idx, (size_t)nq * 8);
+    if (!rc) rc = xfer_d2h(ctx, dist, ctx->m_dist, (size_t)nq * 8);
+    if (rc) return rc;
+    return xfer_flush(ctx);
 }

@@ -250,20 +250,50 @@ __global__ void k_orb_nms(const LevelsDev* __restrict__ L, const uint8_t* __rest
                           const uint8_t* __restrict__ pmask, int with_mask, int32_t* __restrict__ cand_pos,
                           float* __restrict__ cand_resp, int32_t* __restrict__ cnt)
 {
+    // block = 4 waves, tile = 64 columns x 16 rows (wave w takes rows 4w..4w+3).  The survivors of
+    // the whole tile reserve their slots with ONE returning global atomic (a per-wave atomic on a
+    // single counter serialises at ~12 ns each and dominated this kernel).
+    __shared__ int s_cnt[16];
+    __shared__ int s_base;
     const int lvl = blockIdx.z;
     const LevelDev d = L->l[lvl];
-    int x = blockIdx.x * blockDim.x + threadIdx.x + EDGE, y = blockIdx.y + EDGE;
-    if (d.w <= 2 * EDGE || d.h <= 2 * EDGE) return;
-    if (x >= d.w - EDGE || y >= d.h - EDGE) return;
-    const uint8_t* q = pscore + d.off + (size_t)y * d.w + x;
-    const int s = q[0], w = d.w;
-    if (!s) return;
-    if (!(s > q[-1] && s > q[1] && s > q[-w - 1] && s > q[-w] && s > q[-w + 1] && s > q[w - 1] && s > q[w] && s > q[w + 1])) return;
-    if (with_mask && pmask[d.off + (size_t)y * d.w + x] == 0) return;
-    int slot = atomicAdd(&cnt[CNT_CAND + lvl], 1);
-    cand_pos[d.cand_off + slot] = y * d.w + x;
-    cand_resp[d.cand_off + slot] = (float)s;
-    atomicAdd(&cnt[CNT_HIST + lvl * 256 + s], 1);
+    if (d.w <= 2 * EDGE || d.h <= 2 * EDGE) return;  // block-uniform (depends on the level only)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane + EDGE;
+    if (blockIdx.x * 64 + EDGE >= d.w - EDGE || blockIdx.y * 16 + EDGE >= d.h - EDGE) return;  // block-uniform
+    int sc[4];
+    unsigned long long bal[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = blockIdx.y * 16 + wv * 4 + r + EDGE;
+        int s = 0;
+        if (x < d.w - EDGE && y < d.h - EDGE) {
+            const uint8_t* q = pscore + d.off + (size_t)y * d.w + x;
+            const int w = d.w;
+            s = q[0];
+            if (s && !(s > q[-1] && s > q[1] && s > q[-w - 1] && s > q[-w] && s > q[-w + 1] && s > q[w - 1] && s > q[w] && s > q[w + 1])) s = 0;
+            if (s && with_mask && pmask[d.off + (size_t)y * d.w + x] == 0) s = 0;
+        }
+        sc[r] = s;
+        bal[r] = __ballot(s != 0);
+        if (lane == 0) s_cnt[wv * 4 + r] = __popcll(bal[r]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < 16; k++) { const int c = s_cnt[k]; s_cnt[k] = tot; tot += c; }  // exclusive prefix
+        s_base = tot ? atomicAdd(&cnt[CNT_CAND + lvl], tot) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (sc[r]) {
+            const int y = blockIdx.y * 16 + wv * 4 + r + EDGE;
+            const int slot = s_base + s_cnt[wv * 4 + r] + __popcll(bal[r] & ((1ull << lane) - 1ull));
+            cand_pos[d.cand_off + slot] = y * d.w + x;
+            cand_resp[d.cand_off + slot] = (float)sc[r];
+        }
+    }
 }
 
 // retainBest(2*quota) by FAST score: keep every candidate whose score >= the n-th largest
@@ -271,17 +301,27 @@ __global__ void __launch_bounds__(1024) k_orb_fast_select(const LevelsDev* __res
                                                           const float* __restrict__ cand_resp, int32_t* __restrict__ candA_pos,
                                                           int32_t* __restrict__ cnt)
 {
-    __shared__ int s_thr;
+    __shared__ int s_hist[256];
+    __shared__ int s_thr, s_n;
     const int lvl = blockIdx.x;
     const LevelDev d = L->l[lvl];
     const int n = cnt[CNT_CAND + lvl], keep = 2 * d.quota;
+    const int32_t* pos = cand_pos + d.cand_off;
+    const float* resp = cand_resp + d.cand_off;
+    // histogram of the (integer) FAST scores in LDS
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) s_hist[b] = 0;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (keep > 0 && n > keep)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_hist[(int)resp[i] & 255], 1);
+    __syncthreads();
     if (threadIdx.x == 0) {
         int thr = 0;
         if (keep == 0) thr = 1 << 30;
         else if (n > keep) {
             int cum = 0;
             for (int b = 255; b >= 0; b--) {
-                cum += cnt[CNT_HIST + lvl * 256 + b];
+                cum += s_hist[b];
                 if (cum >= keep) { thr = b; break; }
             }
         }
@@ -289,11 +329,18 @@ __global__ void __launch_bounds__(1024) k_orb_fast_select(const LevelsDev* __res
     }
     __syncthreads();
     const int thr = s_thr;
-    for (int i = threadIdx.x; i < n; i += blockDim.x)
-        if ((int)cand_resp[d.cand_off + i] >= thr) {
-            int slot = atomicAdd(&cnt[CNT_A + lvl], 1);
-            candA_pos[d.cand_off + slot] = cand_pos[d.cand_off + i];
-        }
+    const int lane = threadIdx.x & 63;
+    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        const bool keepit = i < n && (int)resp[i] >= thr;
+        const unsigned long long bal = __ballot(keepit);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (keepit) candA_pos[d.cand_off + base + __popcll(bal & ((1ull << lane) - 1ull))] = pos[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[CNT_A + lvl] = s_n;
 }
 
 // Harris response (7x7 block) on the unblurred level
@@ -580,7 +627,7 @@ int orb_run(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img_stride, in
         hipLaunchKernelGGL(k_orb_resize, dim3(div_up(Lh->l[l].w, 256), Lh->l[l].h), dim3(256), 0, ctx->stream, dL, l, ctx->rs_ofs,
                            ctx->rs_coef, ctx->pyr_img, ctx->pyr_mask, with_mask);
     hipLaunchKernelGGL(k_orb_fast, dim3(div_up(w, 64), h, NL), dim3(64), 0, ctx->stream, dL, ctx->pyr_img, ctx->pyr_score);
-    hipLaunchKernelGGL(k_orb_nms, dim3(div_up(w - 2 * EDGE, 64), h - 2 * EDGE, NL), dim3(64), 0, ctx->stream, dL, ctx->pyr_score,
+    hipLaunchKernelGGL(k_orb_nms, dim3(div_up(w - 2 * EDGE, 64), div_up(h - 2 * EDGE, 16), NL), dim3(256), 0, ctx->stream, dL, ctx->pyr_score,
                        ctx->pyr_mask, with_mask, ctx->cand_pos, ctx->cand_resp, ctx->counters);
     hipLaunchKernelGGL(k_orb_fast_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->cand_pos, ctx->cand_resp, ctx->candA_pos, ctx->counters);
     // upper bound of the Harris work list: every candidate of level 0
@@ -615,13 +662,15 @@ static int download_kps(vo_ctx* ctx, FrameSlot& f, float* kp_xy, float* kp_size,
     if (n == 0) return VO_OK;
     const bool any = kp_xy || kp_size || kp_angle || kp_response || kp_octave || desc;
     if (any && n > cap) return vo_fail(ctx, VO_E_CAP, "%d keypoints exceed the output capacity %d", n, cap);
-    if (kp_xy) VO_HIP(ctx, hipMemcpyAsync(kp_xy, f.kp_xy, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (kp_size) VO_HIP(ctx, hipMemcpyAsync(kp_size, f.kp_size, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (kp_angle) VO_HIP(ctx, hipMemcpyAsync(kp_angle, f.kp_angle, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (kp_response) VO_HIP(ctx, hipMemcpyAsync(kp_response, f.kp_resp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (kp_octave) VO_HIP(ctx, hipMemcpyAsync(kp_octave, f.kp_oct, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (desc) VO_HIP(ctx, hipMemcpyAsync(desc, f.desc, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    if (any) VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = VO_OK;
+    if (kp_xy && !rc) rc = xfer_d2h(ctx, kp_xy, f.kp_xy, (size_t)n * 8);
+    if (kp_size && !rc) rc = xfer_d2h(ctx, kp_size, f.kp_size, (size_t)n * 4);
+    if (kp_angle && !rc) rc = xfer_d2h(ctx, kp_angle, f.kp_angle, (size_t)n * 4);
+    if (kp_response && !rc) rc = xfer_d2h(ctx, kp_response, f.kp_resp, (size_t)n * 4);
+    if (kp_octave && !rc) rc = xfer_d2h(ctx, kp_octave, f.kp_oct, (size_t)n * 4);
+    if (desc && !rc) rc = xfer_d2h(ctx, desc, f.desc, (size_t)n * 32);
+    if (rc) return rc;
+    if (any) return xfer_flush(ctx);
     return VO_OK;
 }
 

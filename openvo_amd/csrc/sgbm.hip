@@ -1,27 +1,33 @@
 // StereoSGBM on gfx950: replaces self.stereoSGBM.compute(L, R)
 // [reference stereo_camera.py:23-27,51].  Arithmetic definition: OpenCV 4.x
 // calib3d/src/stereosgbm.cpp (MODE_SGBM 5 paths / MODE_HH 8 paths), all-integer, so the
-// output is bit-exact against the oracle.
+// output is bit-exact against the CPU restatement.
 //
 // Data layout in HBM
 //   planesL[y][x]        2 x u32  : (u,u0,u1) bytes of the x-Sobel channel, then of the raw channel
 //   planesR[k][y][p]     u32      : plane k of (v,v0,v1)x2, packed as value(p) | value(p-1) << 16
-//   C[y][x1][d], S[...]  int16    : cost volume / path sum, d fastest (x1 = x - minX1)
+//   C[y][x1][Dp]         int16    : block cost (+P2), d fastest, Dp = D rounded up to 32, x1 = x - minX1
+//   L[dir][y][x1][Dp]    int16    : one aggregated volume per path direction
 // Kernels
 //   k_sgbm_planes  prefilter + Birchfield-Tomasi half-pixel bounds (elementwise)
-//   k_sgbm_cost    BT pixel cost + (2*SW2+1)^2 box sum, one wave = D/2 disparity PAIRS in
-//                  packed int16x2 lanes, sliding sums in registers; writes C once
-//   k_sgbm_path    one aggregation direction: one wave per scan line, lanes over d (packed
-//                  pairs), DPP neighbour exchange + DPP wave-min; reads C, accumulates S
-//   k_sgbm_wta     last path (x+1,y) fused with WTA / uniqueness / sub-pixel / disp2 / LR check
-//   k_median3, k_ccl_* : medianBlur(3) and filterSpeckles (union-find labelling)
+//   k_sgbm_cost    BT pixel cost + (2*SW2+1)^2 box sum; one lane = one disparity PAIR in packed
+//                  int16x2 math, sliding sums in registers; writes C once
+//   k_sgbm_paths   ALL path directions in one launch.  A scan line lives in one 16-lane DPP row
+//                  (each lane holds Dp/16 consecutive disparities in packed registers), so a wave
+//                  advances 4 independent lines; neighbours d-1/d+1 come from row_shr/row_shl
+//                  (row ends are the MAX_COST sentinels for free), the min over d is a 4-step
+//                  row_ror all-reduce.  Reads C once per direction, writes that direction's L.
+//   k_sgbm_wta     per pixel (16 lanes): S = sat-sum of the L volumes, first minimum, uniqueness,
+//                  sub-pixel, disp2 via atomicMin on (cost, scan order) keys
+//   k_sgbm_lr      left-right consistency check
+//   k_median3, k_ccl_* : medianBlur(3) and filterSpeckles (run-based union-find labelling)
 #include "vo_internal.h"
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 #define MAXC 0x7FFF
 #define MAXC2 0x7FFF7FFFu
+#define D2_EMPTY 0x7FFFFFFF
 
 __device__ __forceinline__ s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -32,33 +38,23 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_add_sat(as_s(a), as_s(b))); }
 __device__ __forceinline__ uint32_t pk_rep(int v) { return (uint32_t)(v & 0xFFFF) * 0x00010001u; }
 
-// lane i <- lane i-1 (lane 0 keeps `fill`)
-__device__ __forceinline__ uint32_t lane_from_prev(uint32_t v, uint32_t fill)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
-}
-// lane i <- lane i+1 (lane 63 keeps `fill`)
-__device__ __forceinline__ uint32_t lane_from_next(uint32_t v, uint32_t fill)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false);
-}
+#define DPP(old, src, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, 0xf, 0xf, false))
+#define ROW_SHL1 0x101
+#define ROW_SHR1 0x111
+#define ROW_ROR(n) (0x120 + (n))
 
-// full-wave unsigned min, result uniform in every lane
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+// all-reduce (min, unsigned) inside each 16-lane row: every lane ends with the row minimum
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v)
 {
-#define DPP_MIN(ctrl, rmask) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false))
-    DPP_MIN(0x111, 0xf);  // row_shr:1
-    DPP_MIN(0x112, 0xf);  // row_shr:2
-    DPP_MIN(0x114, 0xf);  // row_shr:4
-    DPP_MIN(0x118, 0xf);  // row_shr:8
-    DPP_MIN(0x142, 0xa);  // row_bcast:15
-    DPP_MIN(0x143, 0xc);  // row_bcast:31
-#undef DPP_MIN
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    v = min(v, DPP(v, v, ROW_ROR(8)));
+    v = min(v, DPP(v, v, ROW_ROR(4)));
+    v = min(v, DPP(v, v, ROW_ROR(2)));
+    v = min(v, DPP(v, v, ROW_ROR(1)));
+    return v;
 }
 
 struct SgbmGeom {
-    int W, H, W1, D, minD, minX1, P1, P2, ur, d12, ftzero, invalid16, SW2;
+    int W, H, W1, D, Dp, minD, minX1, P1, P2, ur, d12, ftzero, invalid16, SW2;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -130,16 +126,17 @@ __device__ __forceinline__ uint32_t bt_pair(const uint32_t* __restrict__ PL, con
     return acc;
 }
 
-// block = one wave per 64 disparity pairs; tile TX columns x TY rows.  Horizontal window via a
-// register sliding sum over the TX+2*SW2 evaluated columns, vertical window via a register ring.
-// Specialised for SW2 == 2 (blockSize 5, the reference configuration) with a generic fallback.
+// tile TX columns x TY rows per wave-row of lanes.  Horizontal window via a register sliding sum
+// over the TX+2*SW2 evaluated columns, vertical window via a register ring.
 template <int TX, int SW2>
 __global__ void __launch_bounds__(256) k_sgbm_cost(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR,
                                                   SgbmGeom g, int TY, int16_t* __restrict__ C)
 {
     constexpr int WIN = 2 * SW2 + 1;
-    const int dp = threadIdx.x;  // disparity pair index
-    if (2 * dp >= g.D) return;
+    const int dpl = threadIdx.x;  // disparity pair index in the padded layout
+    if (2 * dpl >= g.Dp) return;
+    const bool pad = 2 * dpl >= g.D;
+    const int dp = pad ? 0 : dpl;  // pad lanes compute a valid pair and store the sentinel instead
     const int xa = blockIdx.x * TX, ya = blockIdx.y * TY;
     const size_t plane = (size_t)g.W * g.H;
     const int pbase = g.minX1 - g.minD - 2 * dp;  // right position = x1 + pbase
@@ -149,7 +146,6 @@ __global__ void __launch_bounds__(256) k_sgbm_cost(const uint32_t* __restrict__ 
 #pragma unroll
     for (int j = 0; j < TX; j++) acc[j] = pk_rep(g.P2);
 
-    // horizontal box sums of one image row r into hs[TX]
     auto row_hsum = [&](int r, uint32_t* hs) {
         uint32_t pc[TX + 2 * SW2];
 #pragma unroll
@@ -168,7 +164,6 @@ __global__ void __launch_bounds__(256) k_sgbm_cost(const uint32_t* __restrict__ 
         }
     };
 
-    // prime the ring with rows clamp(ya-SW2 .. ya+SW2)
 #pragma unroll
     for (int k = 0; k < WIN; k++) {
         uint32_t hs[TX];
@@ -182,14 +177,12 @@ __global__ void __launch_bounds__(256) k_sgbm_cost(const uint32_t* __restrict__ 
         for (int k = 0; k < WIN; k++) {
             const int y = y0 + k;
             if (y < yend) {
-                // store row y
 #pragma unroll
                 for (int j = 0; j < TX; j++) {
                     int x1 = xa + j;
                     if (x1 < g.W1)
-                        *(uint32_t*)(C + ((size_t)y * g.W1 + x1) * g.D + 2 * dp) = acc[j];
+                        *(uint32_t*)(C + ((size_t)y * g.W1 + x1) * g.Dp + 2 * dpl) = pad ? MAXC2 : acc[j];
                 }
-                // slide to row y+1: add hsum(clamp(y+1+SW2)), drop hsum(clamp(y-SW2)) == ring slot k
                 if (y + 1 < yend) {
                     uint32_t hs[TX];
                     row_hsum(min(y + 1 + SW2, g.H - 1), hs);
@@ -204,12 +197,14 @@ __global__ void __launch_bounds__(256) k_sgbm_cost(const uint32_t* __restrict__ 
     }
 }
 
-// generic (any block size) fallback: direct box sum, one thread per (x1, d pair), slow but exact
+// any block size: direct box sum, one thread per (x1, d pair); slow but exact
 __global__ void k_sgbm_cost_generic(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR,
                                     SgbmGeom g, int16_t* __restrict__ C)
 {
-    const int dp = threadIdx.x;
-    if (2 * dp >= g.D) return;
+    const int dpl = threadIdx.x;
+    if (2 * dpl >= g.Dp) return;
+    const bool pad = 2 * dpl >= g.D;
+    const int dp = pad ? 0 : dpl;
     const int x1 = blockIdx.x, y = blockIdx.y;
     const size_t plane = (size_t)g.W * g.H;
     const int pbase = g.minX1 - g.minD - 2 * dp;
@@ -221,19 +216,78 @@ __global__ void k_sgbm_cost_generic(const uint32_t* __restrict__ PL, const uint3
             acc = pk_add(acc, bt_pair(PL, PR, plane, g.W, r, xe + g.minX1, xe + pbase));
         }
     }
-    *(uint32_t*)(C + ((size_t)y * g.W1 + x1) * g.D + 2 * dp) = acc;
+    *(uint32_t*)(C + ((size_t)y * g.W1 + x1) * g.Dp + 2 * dpl) = pad ? MAXC2 : acc;
 }
 
 // ---------------------------------------------------------------------------------------
-// path aggregation
+// path aggregation: 16 lanes per scan line, NP packed registers (2*NP disparities) per lane
 // ---------------------------------------------------------------------------------------
-// One lane holds NP packed registers = 2*NP consecutive disparities.  `active` lanes cover
-// [0, D); the others carry MAX_COST so they act as the d = D sentinel.
 template <int NP>
-struct LaneVec { uint32_t r[NP]; };
+struct LV { uint32_t r[NP]; };
 
 template <int NP>
-__device__ __forceinline__ uint32_t lane_min(const LaneVec<NP>& v)
+__device__ __forceinline__ LV<NP> lv_load(const int16_t* p)
+{
+    LV<NP> v;
+    if constexpr (NP == 1) v.r[0] = *(const uint32_t*)p;
+    else if constexpr (NP == 2) { uint2 t = *(const uint2*)p; v.r[0] = t.x; v.r[1] = t.y; }
+    else if constexpr (NP % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < NP / 4; k++) {
+            uint4 t = ((const uint4*)p)[k];
+            v.r[4 * k] = t.x; v.r[4 * k + 1] = t.y; v.r[4 * k + 2] = t.z; v.r[4 * k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; k++) v.r[k] = ((const uint32_t*)p)[k];
+    }
+    return v;
+}
+template <int NP>
+__device__ __forceinline__ void lv_store(int16_t* p, const LV<NP>& v)
+{
+    if constexpr (NP == 1) *(uint32_t*)p = v.r[0];
+    else if constexpr (NP == 2) *(uint2*)p = make_uint2(v.r[0], v.r[1]);
+    else if constexpr (NP % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < NP / 4; k++) ((uint4*)p)[k] = make_uint4(v.r[4 * k], v.r[4 * k + 1], v.r[4 * k + 2], v.r[4 * k + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; k++) ((uint32_t*)p)[k] = v.r[k];
+    }
+}
+template <int NP>
+__device__ __forceinline__ LV<NP> lv_fill(uint32_t x)
+{
+    LV<NP> v;
+#pragma unroll
+    for (int k = 0; k < NP; k++) v.r[k] = x;
+    return v;
+}
+
+// L(d) = C(d) + min(Lp(d), Lp(d-1)+P1, Lp(d+1)+P1, delta) - delta  (C carries +P2, delta = minLp + P2)
+// padreg bit k set: register k lies beyond D and must stay at MAX_COST
+template <int NP>
+__device__ __forceinline__ LV<NP> path_step(const LV<NP>& Cp, const LV<NP>& Lp, uint32_t delta2, uint32_t P1_2, unsigned padreg)
+{
+    LV<NP> out;
+    const uint32_t prev_hi = DPP(MAXC2, Lp.r[NP - 1], ROW_SHR1);  // lane-1's last register; row start keeps the sentinel
+    const uint32_t next_lo = DPP(MAXC2, Lp.r[0], ROW_SHL1);       // lane+1's first register; row end keeps the sentinel
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const uint32_t left = k == 0 ? prev_hi : Lp.r[k - 1];
+        const uint32_t right = k == NP - 1 ? next_lo : Lp.r[k + 1];
+        const uint32_t dm1 = __builtin_amdgcn_alignbit(Lp.r[k], left, 16);   // (L[d-1], L[d])
+        const uint32_t dp1 = __builtin_amdgcn_alignbit(right, Lp.r[k], 16);  // (L[d+1], L[d+2])
+        const uint32_t m = pk_min(pk_min(Lp.r[k], delta2), pk_min(pk_add_sat(dm1, P1_2), pk_add_sat(dp1, P1_2)));
+        const uint32_t L = pk_sub(pk_add(Cp.r[k], m), delta2);
+        out.r[k] = ((padreg >> k) & 1u) ? MAXC2 : L;
+    }
+    return out;
+}
+
+template <int NP>
+__device__ __forceinline__ uint32_t lane_min16(const LV<NP>& v)
 {
     uint32_t m = v.r[0];
 #pragma unroll
@@ -241,242 +295,171 @@ __device__ __forceinline__ uint32_t lane_min(const LaneVec<NP>& v)
     return min(m & 0xFFFFu, m >> 16);
 }
 
-// L(d) = C(d) + min(Lp(d), Lp(d-1)+P1, Lp(d+1)+P1, delta) - delta
-template <int NP>
-__device__ __forceinline__ LaneVec<NP> path_step(const LaneVec<NP>& Cp, const LaneVec<NP>& Lp, uint32_t delta2,
-                                                 uint32_t P1_2, bool active)
-{
-    LaneVec<NP> out;
-    uint32_t prev_hi = lane_from_prev(Lp.r[NP - 1], MAXC2);  // lane-1's last register
-    uint32_t next_lo = lane_from_next(Lp.r[0], MAXC2);       // lane+1's first register
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-        uint32_t left = k == 0 ? prev_hi : Lp.r[k - 1];
-        uint32_t right = k == NP - 1 ? next_lo : Lp.r[k + 1];
-        uint32_t dm1 = __builtin_amdgcn_alignbit(Lp.r[k], left, 16);   // (L[d-1], L[d])
-        uint32_t dp1 = __builtin_amdgcn_alignbit(right, Lp.r[k], 16);  // (L[d+1], L[d+2])
-        uint32_t m = pk_min(pk_min(Lp.r[k], delta2), pk_min(pk_add_sat(dm1, P1_2), pk_add_sat(dp1, P1_2)));
-        uint32_t L = pk_sub(pk_add(Cp.r[k], m), delta2);
-        out.r[k] = active ? L : MAXC2;
-    }
-    return out;
-}
+#define VO_MAX_DIRS 8
+struct PathPlan {
+    int n_dirs;
+    int sx[VO_MAX_DIRS], sy[VO_MAX_DIRS];
+    int nlines[VO_MAX_DIRS];
+    int first_wave[VO_MAX_DIRS + 1];  // prefix sum of ceil(nlines/4)
+};
 
-template <int NP>
-__device__ __forceinline__ LaneVec<NP> load_vec(const int16_t* p)
+template <int NP, int PF>
+__global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ C, int16_t* __restrict__ Lbase, size_t vol,
+                                                   SgbmGeom g, PathPlan plan)
 {
-    LaneVec<NP> v;
-    if (NP == 1) v.r[0] = *(const uint32_t*)p;
-    else {
-        uint2 t = *(const uint2*)p;
-        v.r[0] = t.x;
-        if (NP > 1) v.r[NP - 1] = t.y;
-    }
-    return v;
-}
-template <int NP>
-__device__ __forceinline__ void store_vec(int16_t* p, const LaneVec<NP>& v)
-{
-    if (NP == 1) *(uint32_t*)p = v.r[0];
-    else *(uint2*)p = make_uint2(v.r[0], v.r[NP - 1]);
-}
-
-// One wave per scan line.  dir: step (sx, sy).  Lines are enumerated so that neighbouring
-// waves touch neighbouring memory.  FIRST: S = L (no read), else S = sat(S + L).
-template <int NP, bool FIRST>
-__global__ void __launch_bounds__(256) k_sgbm_path(const int16_t* __restrict__ C, int16_t* __restrict__ S, SgbmGeom g,
-                                                  int sx, int sy, int nlines)
-{
-    const int lane = threadIdx.x & 63;
-    const int line = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (line >= nlines) return;
+    const int lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= plan.first_wave[plan.n_dirs]) return;
+    int dir = 0;
+    while (dir + 1 < plan.n_dirs && wave >= plan.first_wave[dir + 1]) dir++;
+    const int sx = plan.sx[dir], sy = plan.sy[dir];
+    const int line = (wave - plan.first_wave[dir]) * 4 + row;
     const int W1 = g.W1, H = g.H;
-    // start cell and length of this line
-    int x0, y0;
-    if (sy == 0) { y0 = line; x0 = sx > 0 ? 0 : W1 - 1; }
-    else if (sx == 0) { x0 = line; y0 = sy > 0 ? 0 : H - 1; }
-    else {
-        // diagonals: first W1 lines start on the first row in sweep order, the rest on the side
-        int ytop = sy > 0 ? 0 : H - 1;
-        if (line < W1) { x0 = line; y0 = ytop; }
-        else { x0 = sx > 0 ? 0 : W1 - 1; y0 = ytop + sy * (line - W1 + 1); }
-    }
-    int nx = sx > 0 ? W1 - x0 : (sx < 0 ? x0 + 1 : 1 << 30);
-    int ny = sy > 0 ? H - y0 : (sy < 0 ? y0 + 1 : 1 << 30);
-    const int n = min(nx, ny);
-
-    const int nact = g.D / (2 * NP);
-    const bool active = lane < nact;
-    const int lofs = active ? lane * 2 * NP : 0;
-    const uint32_t P1_2 = pk_rep(g.P1);
-    const ptrdiff_t stride = ((ptrdiff_t)sy * W1 + sx) * g.D;
-    const int16_t* cp = C + ((size_t)y0 * W1 + x0) * g.D + lofs;
-    int16_t* sp = S + ((size_t)y0 * W1 + x0) * g.D + lofs;
-
-    LaneVec<NP> Lp;
-#pragma unroll
-    for (int k = 0; k < NP; k++) Lp.r[k] = active ? 0u : MAXC2;  // predecessor outside: zeros, min 0
-    uint32_t delta2 = pk_rep(g.P2);
-
-    constexpr int PF = 8;  // software prefetch depth (steps)
-    LaneVec<NP> cbuf[PF], sbuf[PF];
-#pragma unroll
-    for (int k = 0; k < PF; k++) {
-        if (k < n) {
-            cbuf[k] = load_vec<NP>(cp + (ptrdiff_t)k * stride);
-            if (!FIRST) sbuf[k] = load_vec<NP>(sp + (ptrdiff_t)k * stride);
+    int x0 = 0, y0 = 0, n = 0;
+    if (line < plan.nlines[dir]) {
+        if (sy == 0) { y0 = line; x0 = sx > 0 ? 0 : W1 - 1; }
+        else if (sx == 0) { x0 = line; y0 = sy > 0 ? 0 : H - 1; }
+        else {
+            const int ytop = sy > 0 ? 0 : H - 1;
+            if (line < W1) { x0 = line; y0 = ytop; }
+            else { x0 = sx > 0 ? 0 : W1 - 1; y0 = ytop + sy * (line - W1 + 1); }
         }
+        const int nx = sx > 0 ? W1 - x0 : (sx < 0 ? x0 + 1 : 1 << 30);
+        const int ny = sy > 0 ? H - y0 : (sy < 0 ? y0 + 1 : 1 << 30);
+        n = min(nx, ny);
     }
-    for (int i0 = 0; i0 < n; i0 += PF) {
+    int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
+                   max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
+
+    const int d0 = l16 * 2 * NP;
+    unsigned padreg = 0;
+#pragma unroll
+    for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
+    const uint32_t P1_2 = pk_rep(g.P1);
+    const uint32_t P2_2 = pk_rep(g.P2);
+    const ptrdiff_t stride = ((ptrdiff_t)sy * W1 + sx) * g.Dp;
+    const size_t start = ((size_t)y0 * W1 + x0) * g.Dp + d0;
+    const int16_t* cp = C + start;
+    int16_t* lp = Lbase + (size_t)dir * vol + start;
+
+    LV<NP> Lp;
+#pragma unroll
+    for (int k = 0; k < NP; k++) Lp.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;  // predecessor outside: zeros, min 0
+    uint32_t delta2 = P2_2;
+
+    LV<NP> cbuf[PF];  // PF = software prefetch depth (steps)
+#pragma unroll
+    for (int k = 0; k < PF; k++) cbuf[k] = k < n ? lv_load<NP>(cp + (ptrdiff_t)k * stride) : lv_fill<NP>(0);
+    for (int i0 = 0; i0 < nmax; i0 += PF) {
 #pragma unroll
         for (int k = 0; k < PF; k++) {
             const int i = i0 + k;
-            if (i < n) {
-                LaneVec<NP> Cv = cbuf[k], Sv;
-                if (!FIRST) Sv = sbuf[k];
-                if (i + PF < n) {
-                    cbuf[k] = load_vec<NP>(cp + (ptrdiff_t)(i + PF) * stride);
-                    if (!FIRST) sbuf[k] = load_vec<NP>(sp + (ptrdiff_t)(i + PF) * stride);
-                }
-                LaneVec<NP> L = path_step<NP>(Cv, Lp, delta2, P1_2, active);
-                uint32_t mn = wave_min_u32(lane_min<NP>(L));
-                delta2 = pk_rep((int)mn + g.P2);
+            if (i < nmax) {
+                const LV<NP> Cv = cbuf[k];
+                if (i + PF < n) cbuf[k] = lv_load<NP>(cp + (ptrdiff_t)(i + PF) * stride);
+                const LV<NP> L = path_step<NP>(Cv, Lp, delta2, P1_2, padreg);
+                const uint32_t mn = row_min_u32(lane_min16<NP>(L));
+                delta2 = pk_add(pk_rep((int)mn), P2_2);
                 Lp = L;
-                LaneVec<NP> So;
-#pragma unroll
-                for (int q = 0; q < NP; q++) So.r[q] = FIRST ? L.r[q] : pk_add_sat(Sv.r[q], L.r[q]);
-                if (active) store_vec<NP>(sp + (ptrdiff_t)i * stride, So);
+                if (i < n) lv_store<NP>(lp + (ptrdiff_t)i * stride, L);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// WTA row kernel: (MODE_SGBM) fifth path (x+1,y) swept right-to-left fused with winner-take-all,
-// uniqueness, sub-pixel, disp2 and the LR check.  One wave per image row.
+// winner-take-all: 16 lanes per pixel
 // ---------------------------------------------------------------------------------------
 template <int NP>
-__device__ __forceinline__ int pick_elem(const LaneVec<NP>& v, int d)
+__global__ void __launch_bounds__(256) k_sgbm_wta(const int16_t* __restrict__ Lbase, size_t vol, int nvol, SgbmGeom g,
+                                                 int16_t* __restrict__ disp1, int* __restrict__ d2key)
 {
-    // value of disparity d (wave-uniform) out of the distributed vector
-    const int per = 2 * NP;
-    const int tl = d / per, te = d - tl * per;
-    uint32_t reg = v.r[0];
+    extern __shared__ int16_t s_S[];  // [blockDim/16][Dp]
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long long pid = (long long)blockIdx.x * (blockDim.x >> 4) + grp;
+    const long long npix = (long long)g.W1 * g.H;
+    const bool live = pid < npix;
+    const int y = live ? (int)(pid / g.W1) : 0, x1 = live ? (int)(pid - (long long)y * g.W1) : 0;
+    const int d0 = l16 * 2 * NP;
+    const size_t cell = ((size_t)y * g.W1 + x1) * g.Dp + d0;
+    LV<NP> S = lv_load<NP>(Lbase + cell);
+    for (int v = 1; v < nvol; v++) {
+        const LV<NP> t = lv_load<NP>(Lbase + (size_t)v * vol + cell);
 #pragma unroll
-    for (int k = 1; k < NP; k++) if ((te >> 1) == k) reg = v.r[k];
-    uint32_t got = (uint32_t)__builtin_amdgcn_readlane((int)reg, tl);
-    return (te & 1) ? (int)(got >> 16) : (int)(got & 0xFFFFu);
+        for (int k = 0; k < NP; k++) S.r[k] = pk_add_sat(S.r[k], t.r[k]);
+    }
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const int d = d0 + 2 * k;
+        if (d < g.D) {
+            const uint32_t k0 = ((S.r[k] & 0xFFFFu) << 8) | (uint32_t)d;
+            const uint32_t k1 = ((S.r[k] >> 16) << 8) | (uint32_t)(d + 1);
+            key = min(key, min(k0, k1));
+        }
+    }
+    key = row_min_u32(key);
+    const int minS = (int)(key >> 8), best = (int)(key & 255u);
+    bool viol = false;
+    const int ur100 = 100 - g.ur;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const int d = d0 + 2 * k;
+        if (d < g.D) {
+            const int s0 = (int)(S.r[k] & 0xFFFFu), s1 = (int)(S.r[k] >> 16);
+            viol |= (s0 * ur100 < minS * 100) && (abs(best - d) > 1);
+            viol |= (s1 * ur100 < minS * 100) && (abs(best - d - 1) > 1);
+        }
+    }
+    const unsigned long long bal = __ballot(viol);
+    const bool row_viol = ((bal >> ((threadIdx.x & 48))) & 0xFFFFull) != 0ull;
+    int16_t* myS = s_S + (size_t)grp * g.Dp;
+    lv_store<NP>(myS + d0, S);
+    __syncthreads();
+    if (live && l16 == 0) {
+        const int ximg = x1 + g.minX1;
+        int out = g.invalid16;
+        if (!row_viol) {
+            int dd = best * 16;
+            if (best > 0 && best < g.D - 1) {
+                const int sm = myS[best - 1], sp = myS[best + 1];
+                const int denom2 = max(sm + sp - 2 * minS, 1);
+                dd = best * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
+            }
+            out = dd + g.minD * 16;
+            // disp2: lowest cost wins, ties go to the pixel OpenCV scans first (largest x)
+            const int x2 = ximg - best - g.minD;
+            atomicMin(&d2key[(size_t)y * g.W + x2], (minS << 16) | (0xFFFF - ximg));
+        }
+        disp1[(size_t)y * g.W + ximg] = (int16_t)out;
+    }
 }
 
-template <int NP, bool LAST_PATH>
-__global__ void __launch_bounds__(64) k_sgbm_wta(const int16_t* __restrict__ C, const int16_t* __restrict__ S, SgbmGeom g,
-                                                 int16_t* __restrict__ disp)
+// left-right check (per pixel) on the WTA results
+__global__ void k_sgbm_lr(const int16_t* __restrict__ disp1, const int* __restrict__ d2key, SgbmGeom g, int16_t* __restrict__ out)
 {
-    extern __shared__ int16_t smem[];
-    int16_t* d1row = smem;             // W
-    int16_t* d2row = smem + g.W;       // W
-    int16_t* d2cost = smem + 2 * g.W;  // W
-    const int lane = threadIdx.x, y = blockIdx.x;
-    const int W1 = g.W1, D = g.D;
-    for (int x = lane; x < g.W; x += 64) { d1row[x] = (int16_t)g.invalid16; d2row[x] = (int16_t)g.invalid16; d2cost[x] = MAXC; }
-    __syncthreads();
-
-    const int nact = D / (2 * NP);
-    const bool active = lane < nact;
-    const int lofs = active ? lane * 2 * NP : 0;
-    const uint32_t P1_2 = pk_rep(g.P1);
-    const int16_t* crow = C + (size_t)y * W1 * D + lofs;
-    const int16_t* srow = S + (size_t)y * W1 * D + lofs;
-    LaneVec<NP> Lp;
-#pragma unroll
-    for (int k = 0; k < NP; k++) Lp.r[k] = active ? 0u : MAXC2;
-    uint32_t delta2 = pk_rep(g.P2);
-    const int ur100 = 100 - g.ur;
-
-    constexpr int PF = 4;
-    LaneVec<NP> cbuf[PF], sbuf[PF];
-#pragma unroll
-    for (int k = 0; k < PF; k++) {
-        int x = W1 - 1 - k;
-        if (x >= 0) {
-            if (LAST_PATH) cbuf[k] = load_vec<NP>(crow + (size_t)x * D);
-            sbuf[k] = load_vec<NP>(srow + (size_t)x * D);
-        }
-    }
-    for (int xb = W1 - 1; xb >= 0; xb -= PF) {
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const int x = xb - k;
-            if (x >= 0) {
-                LaneVec<NP> Cv, Sv = sbuf[k];
-                if (LAST_PATH) Cv = cbuf[k];
-                if (x - PF >= 0) {
-                    if (LAST_PATH) cbuf[k] = load_vec<NP>(crow + (size_t)(x - PF) * D);
-                    sbuf[k] = load_vec<NP>(srow + (size_t)(x - PF) * D);
-                }
-                LaneVec<NP> Sf;
-                if (LAST_PATH) {
-                    LaneVec<NP> L = path_step<NP>(Cv, Lp, delta2, P1_2, active);
-                    uint32_t mn = wave_min_u32(lane_min<NP>(L));
-                    delta2 = pk_rep((int)mn + g.P2);
-                    Lp = L;
-#pragma unroll
-                    for (int q = 0; q < NP; q++) Sf.r[q] = active ? pk_add_sat(Sv.r[q], L.r[q]) : MAXC2;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < NP; q++) Sf.r[q] = active ? Sv.r[q] : MAXC2;
-                }
-                // first minimum over d: key = S << 8 | d
-                uint32_t key = 0xFFFFFFFFu;
-#pragma unroll
-                for (int q = 0; q < NP; q++) {
-                    int d = lofs + 2 * q;
-                    uint32_t k0 = ((Sf.r[q] & 0xFFFFu) << 8) | (uint32_t)d;
-                    uint32_t k1 = ((Sf.r[q] >> 16) << 8) | (uint32_t)(d + 1);
-                    key = min(key, min(k0, k1));
-                }
-                if (!active) key = 0xFFFFFFFFu;
-                key = wave_min_u32(key);
-                const int minS = (int)(key >> 8), best = (int)(key & 255u);
-                // uniqueness
-                bool viol = false;
-#pragma unroll
-                for (int q = 0; q < NP; q++) {
-                    int d = lofs + 2 * q;
-                    int s0 = (int)(Sf.r[q] & 0xFFFFu), s1 = (int)(Sf.r[q] >> 16);
-                    viol |= (s0 * ur100 < minS * 100) && (abs(best - d) > 1);
-                    viol |= (s1 * ur100 < minS * 100) && (abs(best - d - 1) > 1);
-                }
-                viol = viol && active;
-                if (__ballot(viol) == 0ull) {
-                    int dd = best * 16;
-                    if (best > 0 && best < D - 1) {
-                        int sm = pick_elem<NP>(Sf, best - 1), spl = pick_elem<NP>(Sf, best + 1);
-                        int denom2 = max(sm + spl - 2 * minS, 1);
-                        dd = best * 16 + ((sm - spl) * 16 + denom2) / (denom2 * 2);
-                    }
-                    if (lane == 0) {
-                        int x2 = x + g.minX1 - best - g.minD;
-                        if (d2cost[x2] > minS) { d2cost[x2] = (int16_t)minS; d2row[x2] = (int16_t)(best + g.minD); }
-                        d1row[x + g.minX1] = (int16_t)(dd + g.minD * 16);
-                    }
-                }
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    const size_t rowo = (size_t)y * g.W;
+    int d1 = g.invalid16;
+    if (x >= g.minX1 && x < g.minX1 + g.W1) {
+        d1 = disp1[rowo + x];
+        if (d1 != g.invalid16) {
+            auto disp2 = [&](int xx) -> int {
+                const int k = d2key[rowo + xx];
+                return k == D2_EMPTY ? g.invalid16 : (0xFFFF - (k & 0xFFFF)) - xx;  // ximg - x2 = d + minD
+            };
+            const int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
+            const int _x = x - _d, x_ = x - d_;
+            bool bad = false;
+            if (0 <= _x && _x < g.W && 0 <= x_ && x_ < g.W) {
+                const int a = disp2(_x), b = disp2(x_);
+                bad = a >= g.minD && abs(a - _d) > g.d12 && b >= g.minD && abs(b - d_) > g.d12;
             }
+            if (bad) d1 = g.invalid16;
         }
     }
-    __syncthreads();
-    // LR consistency check, then write the row
-    for (int x = lane; x < g.W; x += 64) {
-        int d1 = d1row[x];
-        if (x >= g.minX1 && x < g.minX1 + W1 && d1 != g.invalid16) {
-            int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
-            int _x = x - _d, x_ = x - d_;
-            if (0 <= _x && _x < g.W && d2row[_x] >= g.minD && abs(d2row[_x] - _d) > g.d12 &&
-                0 <= x_ && x_ < g.W && d2row[x_] >= g.minD && abs(d2row[x_] - d_) > g.d12)
-                d1 = g.invalid16;
-        }
-        disp[(size_t)y * g.W + x] = (int16_t)d1;
-    }
+    out[rowo + x] = (int16_t)d1;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -501,9 +484,10 @@ __global__ void k_median3(const int16_t* __restrict__ src, int W, int H, int16_t
     dst[(size_t)y * W + x] = (int16_t)p4;
 }
 
-// filterSpeckles as connected-component labelling: union-find over the 4-neighbour graph whose
-// edges join pixels that are both != newVal and differ by <= maxDiff.
-__device__ __forceinline__ int uf_find(int* L, int i)
+// filterSpeckles as connected-component labelling.  Edges join 4-neighbours that are both
+// != newVal and differ by <= maxDiff.  Horizontal runs are labelled by their first pixel in one
+// pass per row; only run heads take part in the union-find, sizes are added once per run.
+__device__ __forceinline__ int uf_find(const int* L, int i)
 {
     int p = L[i];
     while (p != i) { i = p; p = L[i]; }
@@ -521,74 +505,135 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b)
         a = old;
     }
 }
-__global__ void k_ccl_init(const int16_t* __restrict__ img, int n, int newVal, int* __restrict__ L, int* __restrict__ size)
+
+// one block per image row: label[i] = index of the head of i's horizontal run (or -1), runlen[head],
+// size[head] = 0
+__global__ void __launch_bounds__(256) k_ccl_rows(const int16_t* __restrict__ img, int W, int newVal, int maxDiff,
+                                                 int* __restrict__ L, int* __restrict__ runlen, int* __restrict__ size)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    L[i] = img[i] != newVal ? i : -1;
-    size[i] = 0;
+    __shared__ int s_tot[256];
+    const int y = blockIdx.x, tid = threadIdx.x;
+    const int per = (W + 255) / 256;
+    const int xa = tid * per, xb = min(xa + per, W);
+    const int16_t* r = img + (size_t)y * W;
+    // last run start at or before each pixel inside this thread's chunk (-1: none yet)
+    int last = -1;
+    for (int x = xa; x < xb; x++) {
+        const int v = r[x];
+        const bool valid = v != newVal;
+        const bool start = valid && (x == 0 || r[x - 1] == newVal || abs(v - r[x - 1]) > maxDiff);
+        if (start) last = x;
+    }
+    s_tot[tid] = last;
+    __syncthreads();
+    // inclusive prefix max over the threads' chunk results
+    for (int o = 1; o < 256; o <<= 1) {
+        int v = tid >= o ? s_tot[tid - o] : -1;
+        __syncthreads();
+        s_tot[tid] = max(s_tot[tid], v);
+        __syncthreads();
+    }
+    int cur = tid > 0 ? s_tot[tid - 1] : -1;
+    for (int x = xa; x < xb; x++) {
+        const int v = r[x];
+        const size_t i = (size_t)y * W + x;
+        if (v == newVal) { L[i] = -1; continue; }
+        const bool start = x == 0 || r[x - 1] == newVal || abs(v - r[x - 1]) > maxDiff;
+        if (start) { cur = x; size[i] = 0; }
+        L[i] = y * W + cur;
+        const bool end = x == W - 1 || r[x + 1] == newVal || abs(v - r[x + 1]) > maxDiff;
+        if (end) runlen[(size_t)y * W + cur] = x - cur + 1;
+    }
 }
-__global__ void k_ccl_merge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int* __restrict__ L)
+
+__global__ void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int* __restrict__ L)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y + 1 >= H) return;
+    const int i = y * W + x;
+    const int v = img[i], u = img[i + W];
+    if (v == newVal || u == newVal || abs(v - u) > maxDiff) return;
+    const int a = L[i], b = L[i + W];
+    if (x > 0) {
+        // the same pair of runs was already joined by the column to the left
+        const int v1 = img[i - 1], u1 = img[i + W - 1];
+        if (v1 != newVal && u1 != newVal && abs(v1 - u1) <= maxDiff && L[i - 1] == a && L[i + W - 1] == b) return;
+    }
+    uf_union(L, a, b);
+}
+
+// component sizes: every run head (recognised geometrically -- after unions a head's label may
+// point elsewhere) adds its run length to the component root
+__global__ void k_ccl_sizes(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int maxSize,
+                            const int* __restrict__ L, const int* __restrict__ runlen, int* __restrict__ size)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
-    int i = y * W + x;
-    int v = img[i];
+    const int i = y * W + x;
+    const int v = img[i];
     if (v == newVal) return;
-    if (x + 1 < W) { int u = img[i + 1]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(L, i, i + 1); }
-    if (y + 1 < H) { int u = img[i + W]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(L, i, i + W); }
+    const bool start = x == 0 || img[i - 1] == newVal || abs(v - img[i - 1]) > maxDiff;
+    if (!start) return;
+    const int root = uf_find(L, i);
+    // only "size <= maxSize" is ever asked, and the counter only grows: once it is past the limit
+    // further adds are pointless (this removes the contention on the few huge components)
+    if (((volatile int*)size)[root] > maxSize) return;
+    atomicAdd(&size[root], runlen[i]);
 }
-__global__ void k_ccl_count(int n, int* __restrict__ L, int* __restrict__ size)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (L[i] < 0) return;
-    int r = uf_find(L, i);
-    L[i] = r;
-    atomicAdd(&size[r], 1);
-}
+
 __global__ void k_ccl_apply(int16_t* __restrict__ img, int n, int newVal, int maxSize, const int* __restrict__ L,
                             const int* __restrict__ size)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int r = L[i];
-    if (r >= 0 && size[uf_find((int*)L, r)] <= maxSize) img[i] = (int16_t)newVal;
+    const int r = L[i];
+    if (r >= 0 && size[uf_find(L, r)] <= maxSize) img[i] = (int16_t)newVal;
 }
 
 // ---------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------
-template <int NP>
-static int launch_paths(vo_ctx* ctx, const SgbmGeom& g, int mode, int16_t* d_disp)
+static PathPlan make_plan(const SgbmGeom& g, int mode)
 {
-    struct Dir { int sx, sy; };
-    // MODE_SGBM: (x-1,y) (x-1,y-1) (x,y-1) (x+1,y-1) predecessors, then (x+1,y) fused into WTA.
-    // Steps are the negated predecessor offsets.
-    static const Dir d5[] = { {0, 1}, {1, 1}, {-1, 1}, {1, 0} };
-    static const Dir d8[] = { {0, 1}, {1, 1}, {-1, 1}, {1, 0}, {-1, 0}, {1, -1}, {0, -1}, {-1, -1} };
-    const Dir* dirs = mode == 1 ? d8 : d5;
-    const int nd = mode == 1 ? 8 : 4;
+    // steps = negated predecessor offsets.  MODE_SGBM predecessors: (x-1,y) (x+1,y) (x-1,y-1) (x,y-1)
+    // (x+1,y-1); MODE_HH adds (x-1,y+1) (x,y+1) (x+1,y+1).  Longest lines first.
+    static const int sx5[] = { 1, -1, 1, -1, 0 }, sy5[] = { 0, 0, 1, 1, 1 };
+    static const int sx8[] = { 1, -1, 1, -1, 1, -1, 0, 0 }, sy8[] = { 0, 0, 1, 1, -1, -1, 1, -1 };
+    PathPlan p;
+    p.n_dirs = mode == 1 ? 8 : 5;
+    p.first_wave[0] = 0;
+    for (int k = 0; k < p.n_dirs; k++) {
+        p.sx[k] = mode == 1 ? sx8[k] : sx5[k];
+        p.sy[k] = mode == 1 ? sy8[k] : sy5[k];
+        p.nlines[k] = p.sy[k] == 0 ? g.H : (p.sx[k] == 0 ? g.W1 : g.W1 + g.H - 1);
+        p.first_wave[k + 1] = p.first_wave[k] + div_up(p.nlines[k], 4);
+    }
+    for (int k = p.n_dirs; k < VO_MAX_DIRS; k++) { p.sx[k] = p.sy[k] = p.nlines[k] = 0; p.first_wave[k + 1] = p.first_wave[p.n_dirs]; }
+    return p;
+}
+
+template <int NP>
+static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size_t vol, int16_t* d_disp_raw)
+{
     {
         StageTimer t(ctx, VO_T_SGBM_AGG);
-        for (int k = 0; k < nd; k++) {
-            int nlines = dirs[k].sy == 0 ? g.H : (dirs[k].sx == 0 ? g.W1 : g.W1 + g.H - 1);
-            dim3 grid(div_up(nlines, 4)), block(256);
-            if (k == 0)
-                hipLaunchKernelGGL((k_sgbm_path<NP, true>), grid, block, 0, ctx->stream, ctx->C, ctx->S, g, dirs[k].sx, dirs[k].sy, nlines);
-            else
-                hipLaunchKernelGGL((k_sgbm_path<NP, false>), grid, block, 0, ctx->stream, ctx->C, ctx->S, g, dirs[k].sx, dirs[k].sy, nlines);
-        }
+        const int nwaves = plan.first_wave[plan.n_dirs];
+        if (ctx->tune_path_pf == 8 && NP <= 4)
+            hipLaunchKernelGGL((k_sgbm_paths<NP, 8>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan);
+        else if (ctx->tune_path_pf == 2)
+            hipLaunchKernelGGL((k_sgbm_paths<NP, 2>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan);
+        else
+            hipLaunchKernelGGL((k_sgbm_paths<NP, 4>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan);
         VO_CHECK_LAUNCH(ctx);
     }
-    ctx->last_paths = mode == 1 ? 8 : 5;
     {
         StageTimer t(ctx, VO_T_SGBM_WTA);
-        size_t sh = (size_t)3 * g.W * sizeof(int16_t);
-        if (mode == 1)
-            hipLaunchKernelGGL((k_sgbm_wta<NP, false>), dim3(g.H), dim3(64), sh, ctx->stream, ctx->C, ctx->S, g, d_disp);
-        else
-            hipLaunchKernelGGL((k_sgbm_wta<NP, true>), dim3(g.H), dim3(64), sh, ctx->stream, ctx->C, ctx->S, g, d_disp);
+        VO_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->ccl_size, D2_EMPTY, (size_t)g.W * g.H, ctx->stream));
+        const long long npix = (long long)g.W1 * g.H;
+        const size_t sh = (size_t)16 * g.Dp * sizeof(int16_t);
+        hipLaunchKernelGGL((k_sgbm_wta<NP>), dim3((unsigned)((npix + 15) / 16)), dim3(256), sh, ctx->stream, ctx->S, vol, plan.n_dirs,
+                           g, ctx->disp_tmp, ctx->ccl_size);
+        hipLaunchKernelGGL(k_sgbm_lr, dim3(div_up(g.W, 256), g.H), dim3(256), 0, ctx->stream, ctx->disp_tmp, ctx->ccl_size, g, d_disp_raw);
         VO_CHECK_LAUNCH(ctx);
     }
     return VO_OK;
@@ -599,7 +644,7 @@ int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, in
     const SgbmEff& e = ctx->sg;
     if (!e.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");
     SgbmGeom g;
-    g.W = w; g.H = h; g.D = e.D; g.minD = e.minD; g.P1 = e.P1; g.P2 = e.P2; g.ur = e.ur; g.d12 = e.d12;
+    g.W = w; g.H = h; g.D = e.D; g.Dp = (e.D + 31) & ~31; g.minD = e.minD; g.P1 = e.P1; g.P2 = e.P2; g.ur = e.ur; g.d12 = e.d12;
     g.ftzero = e.ftzero; g.SW2 = e.SW2;
     g.minX1 = e.maxD > 0 ? e.maxD : 0;
     int maxX1 = w + (e.minD < 0 ? e.minD : 0);
@@ -607,42 +652,63 @@ int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, in
     g.invalid16 = (e.minD - 1) * 16;
     const int n = w * h;
     if (g.W1 <= 0) {
-        // every pixel invalid
-        std::vector<int16_t> inv((size_t)n, (int16_t)g.invalid16);
+        std::vector<int16_t> inv((size_t)n, (int16_t)g.invalid16);  // every pixel invalid
         VO_HIP(ctx, hipMemcpyAsync(d_disp, inv.data(), (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream));
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->last_cells = 0;
         return VO_OK;
     }
-    const size_t cells = (size_t)g.W1 * h * g.D;
-    if (cells > ctx->vol_cells || e.D > 256)
-        return vo_fail(ctx, VO_E_CAP, "cost volume %zu cells exceeds the capacity given to vo_create (or D > 256)", cells);
-    ctx->last_cells = (int64_t)cells;
+    const size_t vol = (size_t)g.W1 * h * g.Dp;
+    if (vol > ctx->vol_cells || e.D > 256)
+        return vo_fail(ctx, VO_E_CAP, "cost volume %zu cells exceeds the capacity given to vo_create (or D > 256)", vol);
+    const PathPlan plan = make_plan(g, e.mode);
+    if (plan.n_dirs > ctx->S_vols) {
+        // MODE_HH needs 8 path volumes; grow once
+        if (ctx->S) (void)hipFree(ctx->S);
+        ctx->S = nullptr; ctx->S_vols = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->S, ctx->vol_cells * sizeof(int16_t) * plan.n_dirs + 256));
+        ctx->S_vols = plan.n_dirs;
+    }
+    ctx->last_cells = (int64_t)g.W1 * h * g.D;
+    ctx->last_paths = plan.n_dirs;
     {
         StageTimer t(ctx, VO_T_SGBM_COST);
         hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
                            ctx->planesL, ctx->planesR);
-        const int bx = ((g.D / 2 + 63) / 64) * 64;
+        const int bx = ((g.Dp / 2 + 63) / 64) * 64;
         if (g.SW2 == 2) {
-            constexpr int TX = 8;
-            const int TY = 60;
-            hipLaunchKernelGGL((k_sgbm_cost<TX, 2>), dim3(div_up(g.W1, TX), div_up(h, TY)), dim3(bx), 0, ctx->stream,
-                               ctx->planesL, ctx->planesR, g, TY, ctx->C);
+            const int TY = ctx->tune_cost_ty;
+            if (ctx->tune_cost_tx == 4)
+                hipLaunchKernelGGL((k_sgbm_cost<4, 2>), dim3(div_up(g.W1, 4), div_up(h, TY)), dim3(bx), 0, ctx->stream,
+                                   ctx->planesL, ctx->planesR, g, TY, ctx->C);
+            else
+                hipLaunchKernelGGL((k_sgbm_cost<8, 2>), dim3(div_up(g.W1, 8), div_up(h, TY)), dim3(bx), 0, ctx->stream,
+                                   ctx->planesL, ctx->planesR, g, TY, ctx->C);
         } else {
             hipLaunchKernelGGL(k_sgbm_cost_generic, dim3(g.W1, h), dim3(bx), 0, ctx->stream, ctx->planesL, ctx->planesR, g, ctx->C);
         }
         VO_CHECK_LAUNCH(ctx);
     }
-    int rc = g.D > 128 ? launch_paths<2>(ctx, g, e.mode, ctx->disp_raw) : launch_paths<1>(ctx, g, e.mode, ctx->disp_raw);
+    int rc;
+    switch (g.Dp / 32) {
+        case 1: rc = launch_agg<1>(ctx, g, plan, vol, ctx->disp_raw); break;
+        case 2: rc = launch_agg<2>(ctx, g, plan, vol, ctx->disp_raw); break;
+        case 3: rc = launch_agg<3>(ctx, g, plan, vol, ctx->disp_raw); break;
+        case 4: rc = launch_agg<4>(ctx, g, plan, vol, ctx->disp_raw); break;
+        case 5: rc = launch_agg<5>(ctx, g, plan, vol, ctx->disp_raw); break;
+        case 6: rc = launch_agg<6>(ctx, g, plan, vol, ctx->disp_raw); break;
+        case 7: rc = launch_agg<7>(ctx, g, plan, vol, ctx->disp_raw); break;
+        default: rc = launch_agg<8>(ctx, g, plan, vol, ctx->disp_raw); break;
+    }
     if (rc) return rc;
     {
         StageTimer t(ctx, VO_T_SGBM_POST);
         hipLaunchKernelGGL(k_median3, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, ctx->disp_raw, w, h, d_disp);
         if (e.speckleWindow > 0) {
             const int newVal = g.invalid16, maxDiff = 16 * e.speckleRange;
-            hipLaunchKernelGGL(k_ccl_init, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_disp, n, newVal, ctx->ccl_label, ctx->ccl_size);
-            hipLaunchKernelGGL(k_ccl_merge, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, ctx->ccl_label);
-            hipLaunchKernelGGL(k_ccl_count, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, n, ctx->ccl_label, ctx->ccl_size);
+            hipLaunchKernelGGL(k_ccl_rows, dim3(h), dim3(256), 0, ctx->stream, d_disp, w, newVal, maxDiff, ctx->ccl_label, ctx->ccl_runlen, ctx->ccl_size);
+            hipLaunchKernelGGL(k_ccl_vmerge, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, ctx->ccl_label);
+            hipLaunchKernelGGL(k_ccl_sizes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ccl_label, ctx->ccl_runlen, ctx->ccl_size);
             hipLaunchKernelGGL(k_ccl_apply, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_disp, n, newVal, e.speckleWindow, ctx->ccl_label, ctx->ccl_size);
         }
         VO_CHECK_LAUNCH(ctx);

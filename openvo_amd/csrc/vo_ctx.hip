@@ -1,6 +1,7 @@
 // Context, configuration, image front-end (cvtColor / remap), lazy downloads.
 // Replaces the cv2 calls of StereoCamera.compute_3d [reference stereo_camera.py:43-55].
 #include <stdarg.h>
+#include <stdlib.h>
 #include "vo_internal.h"
 
 int vo_fail(vo_ctx* ctx, int code, const char* fmt, ...)
@@ -15,6 +16,63 @@ int vo_fail(vo_ctx* ctx, int code, const char* fmt, ...)
 }
 
 static thread_local std::string g_create_err;
+
+// ---- pinned transfer arena ---------------------------------------------------------------
+static const size_t ARENA_BASE = 4096;
+
+static void* arena_take(vo_ctx* ctx, size_t bytes)
+{
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (ARENA_BASE + ctx->arena_off + need > ctx->pinned_bytes) return nullptr;
+    void* p = (char*)ctx->pinned + ARENA_BASE + ctx->arena_off;
+    ctx->arena_off += need;
+    return p;
+}
+
+int xfer_flush(vo_ctx* ctx)
+{
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (const auto& c : ctx->pending) memcpy(c.dst, c.src, c.bytes);
+    ctx->pending.clear();
+    ctx->arena_off = 0;
+    return VO_OK;
+}
+
+int xfer_h2d(vo_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes)
+{
+    if (bytes == 0) return VO_OK;
+    void* st = arena_take(ctx, bytes);
+    if (!st && bytes + 64 <= ctx->pinned_bytes - ARENA_BASE) {
+        int rc = xfer_flush(ctx);  // arena full: drain what is in flight, then reuse it
+        if (rc) return rc;
+        st = arena_take(ctx, bytes);
+    }
+    if (!st) {  // larger than the arena: plain copy
+        VO_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return VO_OK;
+    }
+    memcpy(st, host_src, bytes);
+    VO_HIP(ctx, hipMemcpyAsync(dev_dst, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return VO_OK;
+}
+
+int xfer_d2h(vo_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes)
+{
+    if (bytes == 0) return VO_OK;
+    void* st = arena_take(ctx, bytes);
+    if (!st && bytes + 64 <= ctx->pinned_bytes - ARENA_BASE) {
+        int rc = xfer_flush(ctx);
+        if (rc) return rc;
+        st = arena_take(ctx, bytes);
+    }
+    if (!st) {
+        VO_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return VO_OK;
+    }
+    VO_HIP(ctx, hipMemcpyAsync(st, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pending.push_back({host_dst, st, bytes});
+    return VO_OK;
+}
 
 template <typename T>
 static int dalloc(vo_ctx* ctx, T** p, size_t count)
@@ -72,9 +130,12 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->stage_in, ctx->stage_bytes * 2);
     for (int c = 0; c < 2; c++) { DALLOC(ctx->map1[c], npx * 2); DALLOC(ctx->map2[c], npx); }
     DALLOC(ctx->planesL, npx * 2); DALLOC(ctx->planesR, npx * 6);
-    ctx->vol_cells = npx * (size_t)max_disp;
-    DALLOC(ctx->C, ctx->vol_cells); DALLOC(ctx->S, ctx->vol_cells);
-    DALLOC(ctx->disp_raw, npx); DALLOC(ctx->ccl_label, npx); DALLOC(ctx->ccl_size, npx);
+    ctx->vol_cells = npx * (size_t)((max_disp + 31) & ~31);
+    DALLOC(ctx->C, ctx->vol_cells);
+    DALLOC(ctx->S, ctx->vol_cells * 5);   // one volume per MODE_SGBM path; grown to 8 for MODE_HH
+    ctx->S_vols = 5;
+    DALLOC(ctx->disp_raw, npx); DALLOC(ctx->disp_tmp, npx);
+    DALLOC(ctx->ccl_label, npx); DALLOC(ctx->ccl_size, npx); DALLOC(ctx->ccl_runlen, npx);
     // ORB: 8-level pyramid is < 3.2x the base image
     ctx->pyr_bytes = npx * 4;
     DALLOC(ctx->pyr_img, ctx->pyr_bytes); DALLOC(ctx->pyr_blur, ctx->pyr_bytes);
@@ -99,10 +160,13 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->xy_a, (size_t)ctx->kp_cap * 2); DALLOC(ctx->xy_b, (size_t)ctx->kp_cap * 2);
     DALLOC(ctx->mq_idx, ctx->kp_cap); DALLOC(ctx->mt_idx, ctx->kp_cap);
     DALLOC(ctx->red, 4096);
-    ctx->pinned_bytes = 1 << 20;
+    ctx->pinned_bytes = 8 << 20;
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         g_create_err = "hipHostMalloc failed"; vo_destroy(ctx); return VO_E_HIP;
     }
+    if (const char* e1 = getenv("VO_COST_TX")) ctx->tune_cost_tx = atoi(e1) == 4 ? 4 : 8;
+    if (const char* e2 = getenv("VO_COST_TY")) { int v = atoi(e2); if (v >= 5 && v <= 2000) ctx->tune_cost_ty = (v / 5) * 5; }
+    if (const char* e3 = getenv("VO_PATH_PF")) { int v = atoi(e3); if (v == 2 || v == 4 || v == 8) ctx->tune_path_pf = v; }
     *out = ctx;
     return VO_OK;
 }
@@ -118,13 +182,15 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         for (void* p : ps) if (p) (void)hipFree(p);
     }
     void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
-                   ctx->C, ctx->S, ctx->disp_raw, ctx->ccl_label, ctx->ccl_size, ctx->pyr_img, ctx->pyr_blur,
+                   ctx->C, ctx->S, ctx->disp_raw, ctx->disp_tmp, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->pyr_img, ctx->pyr_blur,
                    ctx->pyr_mask, ctx->pyr_score, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->cand_pos,
                    ctx->cand_resp, ctx->candA_pos, ctx->candA_resp, ctx->candB_pos, ctx->candB_resp, ctx->kp_pos, ctx->pyr_tmp16, ctx->counters, ctx->host_mask_dev, ctx->mq, ctx->mt,
                    ctx->m_idx, ctx->m_dist, ctx->pts_a, ctx->pts_b, ctx->st_a, ctx->st_b, ctx->xy_a, ctx->xy_b,
                    ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws };
     for (void* p : ps) if (p) (void)hipFree(p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->staged) (void)hipFree(ctx->staged);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -242,7 +308,7 @@ static int check_slot(vo_ctx* ctx, int slot)
 
 // upload one camera image into dst (gray, rectified)
 static int ingest(vo_ctx* ctx, int cam, const uint8_t* host, int w, int h, int channels, int preprocessed, uint8_t* dst,
-                  uint8_t* stage)
+                  uint8_t* stage, hipMemcpyKind kind = hipMemcpyHostToDevice)
 {
     const size_t n = (size_t)w * h;
     const bool need_remap = !preprocessed;
@@ -250,10 +316,10 @@ static int ingest(vo_ctx* ctx, int cam, const uint8_t* host, int w, int h, int c
         return vo_fail(ctx, VO_E_STATE, "rectification maps for camera %d not set for %dx%d", cam, w, h);
     uint8_t* gray = need_remap ? stage + n * 3 : dst;  // gray staging behind the colour staging
     if (channels == 3) {
-        VO_HIP(ctx, hipMemcpyAsync(stage, host, n * 3, hipMemcpyHostToDevice, ctx->stream));
+        VO_HIP(ctx, hipMemcpyAsync(stage, host, n * 3, kind, ctx->stream));
         hipLaunchKernelGGL(k_bgr2gray, dim3(div_up((int)n, 256)), dim3(256), 0, ctx->stream, stage, (int)n, gray);
     } else {
-        VO_HIP(ctx, hipMemcpyAsync(gray, host, n, hipMemcpyHostToDevice, ctx->stream));
+        VO_HIP(ctx, hipMemcpyAsync(gray, host, n, kind, ctx->stream));
     }
     if (need_remap)
         hipLaunchKernelGGL(k_remap, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, gray, w, h, ctx->map1[cam],
@@ -278,6 +344,49 @@ extern "C" int vo_upload_pair(vo_ctx* ctx, int slot, const uint8_t* left, const 
     if (rc) return rc;
     // the second ingest reuses the staging area: order on the stream makes that safe
     rc = ingest(ctx, 1, right, w, h, channels, preprocessed, f.right, ctx->stage_in);
+    if (rc) return rc;
+    f.w = w; f.h = h; f.has_pair = true; f.has_disp = false; f.has_kp = false; f.n_kp = 0;
+    return VO_OK;
+}
+
+// ---- inputs kept resident in HBM (streaming ingest / benchmarking) -----------------------
+extern "C" int vo_stage_pairs_alloc(vo_ctx* ctx, int n, int w, int h, int channels)
+{
+    if (!ctx || n <= 0 || (channels != 1 && channels != 3)) return vo_fail(ctx, VO_E_ARG, "vo_stage_pairs_alloc: bad argument");
+    if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context", w, h);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->staged) { (void)hipFree(ctx->staged); ctx->staged = nullptr; }
+    ctx->staged_n = 0;
+    const size_t per = (size_t)w * h * channels;
+    VO_HIP(ctx, hipMalloc((void**)&ctx->staged, per * 2 * n));
+    ctx->staged_n = n; ctx->staged_w = w; ctx->staged_h = h; ctx->staged_ch = channels;
+    return VO_OK;
+}
+
+extern "C" int vo_stage_pair(vo_ctx* ctx, int index, const uint8_t* left, const uint8_t* right)
+{
+    if (!ctx || !left || !right || index < 0 || index >= ctx->staged_n) return vo_fail(ctx, VO_E_ARG, "vo_stage_pair: bad index");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t per = (size_t)ctx->staged_w * ctx->staged_h * ctx->staged_ch;
+    VO_HIP(ctx, hipMemcpyAsync(ctx->staged + per * 2 * index, left, per, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(ctx->staged + per * (2 * index + 1), right, per, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (index < 0 || index >= ctx->staged_n) return vo_fail(ctx, VO_E_ARG, "vo_load_staged_pair: bad index");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    FrameSlot& f = ctx->slots[slot];
+    const int w = ctx->staged_w, h = ctx->staged_h;
+    const size_t per = (size_t)w * h * ctx->staged_ch;
+    StageTimer t(ctx, VO_T_UPLOAD);
+    rc = ingest(ctx, 0, ctx->staged + per * 2 * index, w, h, ctx->staged_ch, preprocessed, f.left, ctx->stage_in, hipMemcpyDeviceToDevice);
+    if (rc) return rc;
+    rc = ingest(ctx, 1, ctx->staged + per * (2 * index + 1), w, h, ctx->staged_ch, preprocessed, f.right, ctx->stage_in, hipMemcpyDeviceToDevice);
     if (rc) return rc;
     f.w = w; f.h = h; f.has_pair = true; f.has_disp = false; f.has_kp = false; f.n_kp = 0;
     return VO_OK;
@@ -415,13 +524,50 @@ extern "C" int vo_slot_num_keypoints(vo_ctx* ctx, int slot, int* n_out)
 extern "C" int vo_enable_timing(vo_ctx* ctx, int on)
 {
     if (!ctx) return VO_E_ARG;
+    // on = 1: every stage; on > 1: bit mask (1 << stage) << 1 of the stages to time; 0: off
     ctx->timing = on != 0;
+    ctx->timing_mask = on == 1 ? ~0u : (unsigned)on >> 1;
     return VO_OK;
+}
+
+// resolve the event pairs recorded so far (events are recorded without blocking the stream)
+static void resolve_events(vo_ctx* ctx)
+{
+    if (ctx->ev_used == 0) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (size_t i = 0; i < ctx->ev_used; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]) == hipSuccess) {
+            ctx->t_ms[ctx->ev_stage[i]] += ms;
+            ctx->t_n[ctx->ev_stage[i]] += 1;
+        }
+    }
+    ctx->ev_used = 0;
+}
+
+StageTimer::StageTimer(vo_ctx* ctx, int s) : c(ctx), stage(s), idx(-1)
+{
+    if (!c->timing || !((c->timing_mask >> s) & 1u)) return;
+    if (c->ev_used * 2 + 2 > c->ev_pool.size()) {
+        if (c->ev_pool.size() >= 32768) resolve_events(c);
+        else
+            for (int k = 0; k < 512; k++) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) c->ev_pool.push_back(e); }
+    }
+    if (c->ev_used * 2 + 2 > c->ev_pool.size()) return;
+    idx = (long)c->ev_used++;
+    if (c->ev_stage.size() <= (size_t)idx) c->ev_stage.resize(idx + 1);
+    c->ev_stage[idx] = s;
+    (void)hipEventRecord(c->ev_pool[2 * idx], c->stream);
+}
+StageTimer::~StageTimer()
+{
+    if (idx >= 0) (void)hipEventRecord(c->ev_pool[2 * idx + 1], c->stream);
 }
 
 extern "C" int vo_get_timings(vo_ctx* ctx, double* ms_out, int64_t* launches_out, int reset)
 {
     if (!ctx) return VO_E_ARG;
+    resolve_events(ctx);
     for (int i = 0; i < VO_T_NSTAGES; i++) {
         if (ms_out) ms_out[i] = ctx->t_ms[i];
         if (launches_out) launches_out[i] = ctx->t_n[i];

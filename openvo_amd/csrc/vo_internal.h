@@ -72,7 +72,10 @@ struct vo_ctx {
     int16_t* C = nullptr;          // cost volume
     int16_t* S = nullptr;          // aggregated volume
     size_t vol_cells = 0;
+    int S_vols = 0;                // path volumes allocated behind S
     int16_t* disp_raw = nullptr;
+    int16_t* disp_tmp = nullptr;   // WTA output before the LR check
+    int32_t* ccl_runlen = nullptr;
     int32_t* ccl_label = nullptr;
     int32_t* ccl_size = nullptr;
     int64_t last_cells = 0;
@@ -122,11 +125,25 @@ struct vo_ctx {
     size_t clique_ws_bytes = 0;
     float* img3_ws = nullptr;
     size_t img3_ws_bytes = 0;
-    void* pinned = nullptr;        // small pinned host buffer for readbacks
+    void* pinned = nullptr;        // pinned host buffer: first 4 KB scalar readbacks, rest = transfer arena
     size_t pinned_bytes = 0;
+    size_t arena_off = 0;          // bump pointer into the arena (reset by xfer_flush)
+    struct PendingCopy { void* dst; const void* src; size_t bytes; };
+    std::vector<PendingCopy> pending;  // device->host copies staged in the arena, scattered at flush
+
+    // inputs staged in HBM
+    uint8_t* staged = nullptr;
+    int staged_n = 0, staged_w = 0, staged_h = 0, staged_ch = 1;
+
+    // tuning knobs (environment: VO_COST_TX, VO_COST_TY, VO_PATH_PF), read once in vo_create
+    int tune_cost_tx = 4, tune_cost_ty = 120, tune_path_pf = 8;
 
     // timing
     bool timing = false;
+    unsigned timing_mask = ~0u;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_stage;
+    size_t ev_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double t_ms[VO_T_NSTAGES] = {0};
     int64_t t_n[VO_T_NSTAGES] = {0};
@@ -144,25 +161,24 @@ int vo_fail(vo_ctx* ctx, int code, const char* fmt, ...);
 
 #define VO_CHECK_LAUNCH(ctx) VO_HIP(ctx, hipGetLastError())
 
+// hipEvent pair around a stage, recorded on the context stream WITHOUT blocking it; the pairs are
+// resolved in vo_get_timings.
 struct StageTimer {
     vo_ctx* c;
     int stage;
-    StageTimer(vo_ctx* ctx, int s) : c(ctx), stage(s) {
-        if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
-    }
-    ~StageTimer() {
-        if (c->timing) {
-            (void)hipEventRecord(c->ev1, c->stream);
-            (void)hipEventSynchronize(c->ev1);
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-            c->t_ms[stage] += ms;
-            c->t_n[stage] += 1;
-        }
-    }
+    long idx;
+    StageTimer(vo_ctx* ctx, int s);
+    ~StageTimer();
 };
 
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Small host<->device transfers go through the pinned arena: asynchronous copies from / to
+// pageable memory make the runtime pin and unpin the pages on every call (hundreds of
+// microseconds each).  xfer_d2h defers the final host memcpy to xfer_flush (which synchronises).
+int xfer_h2d(vo_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+int xfer_d2h(vo_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+int xfer_flush(vo_ctx* ctx);
 
 // implemented in the per-stage files
 int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);

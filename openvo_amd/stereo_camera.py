@@ -13,6 +13,14 @@ from . import _native, calib
 from .features import DeviceImage, FrameHandle, StereoSGBM
 
 
+class StagedPair:
+    """Handle of an input pair already resident in HBM (see StereoCamera.stage_pairs); pass it as
+    `img_left` (with img_right=None) to compute_3d / StereoOdometer.update."""
+
+    def __init__(self, index):
+        self.index = int(index)
+
+
 class StereoCamera:
     @classmethod
     def from_pfiles(cls, left_cam_file, right_cam_file, rect_file, sgbm_file, img_size, **kw):
@@ -74,6 +82,12 @@ class StereoCamera:
         self._next_slot = (s + 1) % n
         return s, weakref
 
+    def stage_pairs(self, pairs):
+        """Upload (left, right) pairs once and keep them in HBM; returns StagedPair handles.
+        Not in the reference: lets a caller overlap / amortise host-to-device ingest."""
+        self._ctx.stage_pairs(pairs)
+        return [StagedPair(i) for i in range(len(pairs))]
+
     # ---- reference API ----------------------------------------------------------------------
     def undistort_rectify_left(self, img):
         return self._rectify(0, img)
@@ -98,15 +112,20 @@ class StereoCamera:
     def compute_3d(self, img_left, img_right, preprocessed=False):
         """-> (img_3d float32 HcxWcx3, disparity float32 HcxWc, img_left uint8 HcxWc), cropped;
         each is a DeviceImage (np.asarray(x) or x[...] materialises it)."""
-        img_left, img_right = np.asarray(img_left), np.asarray(img_right)
-        if img_left.ndim != img_right.ndim:
+        staged = isinstance(img_left, StagedPair)
+        if not staged:
+            img_left, img_right = np.asarray(img_left), np.asarray(img_right)
+        if not staged and img_left.ndim != img_right.ndim:
             # the reference converts each image independently (stereo_camera.py:44-47)
             if img_left.ndim == 3:
                 img_left = self._ctx.cvt_bgr2gray(img_left)
             if img_right.ndim == 3:
                 img_right = self._ctx.cvt_bgr2gray(img_right)
         slot, weakref = self._acquire_slot()
-        w, h = self._ctx.upload_pair(slot, img_left, img_right, preprocessed)
+        if staged:
+            w, h = self._ctx.load_staged_pair(slot, img_left.index, preprocessed)
+        else:
+            w, h = self._ctx.upload_pair(slot, img_left, img_right, preprocessed)
         self._ctx.sgbm_compute(slot)
         vr = self.valid_region_left
         # numpy slice semantics (negative / oversized bounds clip)
