@@ -128,6 +128,17 @@ int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int32_t* 
                     int32_t* t_idx, float* pts_a /*cap*3*/, float* pts_b, uint8_t* status_a,
                     uint8_t* status_b, int cap, int* m_out);
 
+/* fused pair step with ONE host synchronisation: point_clouds [:162-175] followed by the filtering
+ * and fitting part of point_cloud_transform [:177-205] for two device-resident slots.
+ * counts4 = {M matches after the ratio test, n1 after the rigid-body filter (= M when
+ * rigidity_thr <= 0), n2 after the outlier pass (= n1 when it did not run), flags}; flags bit0: a
+ * 3-D lookup had no usable tap (reference raises ZeroDivisionError), bit1: NaN residual.
+ * rc2 = Umeyama status of {first fit, final fit}: 0 ok, 1 not attempted, -1 fewer than 3 points,
+ * -2 "Points cannot be colinear".  T2_12 = final 3x4 transform (valid when rc2[1] == 0); T1_12 may be
+ * NULL.  The caller applies the motion gates [:207-221]. */
+int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int min_matches, double rigidity_thr,
+                 double outlier_thr, int32_t* counts4, int32_t* rc2, double* T1_12, double* T2_12);
+
 /* pose (stereo_odometer.py:82-105,177-223) ---------------------------------------------- */
 /* cv2.estimateAffine3D(src, dst, force_rotation) Umeyama [:190,204]: T 3x4 row-major, scale */
 int vo_umeyama(vo_ctx* ctx, const float* src /*m*3*/, const float* dst, int m, int force_rotation,

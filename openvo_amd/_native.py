@@ -25,7 +25,7 @@ SYMBOLS = [
     "vo_download_left", "vo_download_right", "vo_cvt_bgr2gray", "vo_remap", "vo_reproject_to_3d",
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
-    "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
+    "vo_pose_pair", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
     "vo_sgbm_last_geometry",
 ]
 
@@ -92,6 +92,7 @@ def lib():
         L.vo_points3d_at.argtypes = [vp, ci, vp, ci, vp, vp]
         L.vo_bilinear_at.argtypes = [vp, vp, ci, ci, vp, ci, vp, vp]
         L.vo_point_clouds.argtypes = [vp, ci, ci, cd, vp, vp, vp, vp, vp, vp, ci, vp]
+        L.vo_pose_pair.argtypes = [vp, ci, ci, cd, ci, cd, cd, vp, vp, vp, vp]
         L.vo_umeyama.argtypes = [vp, vp, vp, ci, ci, vp, vp]
         L.vo_rigid_clique.argtypes = [vp, vp, vp, ci, cd, vp]
         L.vo_rodrigues.argtypes = [vp, vp]
@@ -324,6 +325,17 @@ class Context:
                                            _p(sa), _p(sb), cap, ctypes.byref(m)))
         m = m.value
         return q[:m], t[:m], pa[:m], pb[:m], sa[:m], sb[:m]
+
+    def pose_pair(self, slot_a, slot_b, ratio, min_matches, rigidity_thr, outlier_thr):
+        """Fused match + ratio + 3-D lookup + clique filter + outlier pass + Umeyama for two slots.
+        Returns (counts[M, n1, n2, flags], rc[first, final], T1 3x4, T2 3x4)."""
+        counts = np.zeros(4, np.int32)
+        rc = np.ones(2, np.int32)
+        T1 = np.full((3, 4), np.nan)
+        T2 = np.full((3, 4), np.nan)
+        self._ck(self._lib.vo_pose_pair(self._h, int(slot_a), int(slot_b), float(ratio), int(min_matches),
+                                        float(rigidity_thr), float(outlier_thr), _p(counts), _p(rc), _p(T1), _p(T2)))
+        return counts, rc, T1, T2
 
     def umeyama(self, src, dst, force_rotation=True):
         src, dst = _c(src, np.float32).reshape(-1, 3), _c(dst, np.float32).reshape(-1, 3)

@@ -633,3 +633,509 @@ extern "C" int vo_rigid_clique(vo_ctx* ctx, const float* prev, const float* cur,
     if ((rc = xfer_d2h(ctx, mask_out, d_mask, (size_t)m * 8))) return rc;
     return xfer_flush(ctx);
 }
+
+// =========================================================================================
+// Fused pair step: point_clouds + point_cloud_transform of two device-resident frames
+// [reference stereo_odometer.py:162-175,177-205] with ONE host synchronisation.  Every count
+// (matches M, survivors of the clique filter n1, of the outlier pass n2) stays on the device;
+// kernels are launched for the upper bound and read the live count.  The host only applies the
+// motion gates [:207-221] to the returned transform.
+// =========================================================================================
+struct PoseOut {
+    int M, n1, n2, flags;   // flags bit0: a 3-D lookup had no usable tap (ZeroDivisionError); bit1: NaN residual
+    int rc1, rc2, pad0, pad1;  // Umeyama status of the first / final fit: 0 ok, -1 < 3 points, -2 colinear
+    double T1[12], s1, T2[12], s2;
+};
+
+__global__ void k_points3d_dev(TapDisp tap, int cw, int ch, const float* __restrict__ xy, const int* __restrict__ n_dev,
+                               float* __restrict__ xyz, uint8_t* __restrict__ status, int* __restrict__ flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_dev) return;
+    bilinear_one(tap, cw, ch, xy[2 * i], xy[2 * i + 1], xyz + 3 * (size_t)i, status + i);
+    if (status[i] == 2) atomicOr(flags, 1);
+}
+
+// consistency matrix as bit rows: bits[i][w] bit b = | ||cur_i-cur_j|| - ||prev_i-prev_j|| | < thr, j = 64 w + b
+__global__ void k_pose_cons_bits(const float* __restrict__ prev, const float* __restrict__ cur, const int* __restrict__ m_dev,
+                                 float thr, unsigned long long* __restrict__ bits, int words_cap, int* __restrict__ ncons)
+{
+    const int m = *m_dev;
+    const int i = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    if (i >= m || blockIdx.x * 64 >= m) return;
+    bool c = false;
+    if (j < m) {
+        float ax = cur[3 * i] - cur[3 * j], ay = cur[3 * i + 1] - cur[3 * j + 1], az = cur[3 * i + 2] - cur[3 * j + 2];
+        float bx = prev[3 * i] - prev[3 * j], by = prev[3 * i + 1] - prev[3 * j + 1], bz = prev[3 * i + 2] - prev[3 * j + 2];
+        float na = sqrtf((ax * ax + ay * ay) + az * az), nb = sqrtf((bx * bx + by * by) + bz * bz);
+        c = fabsf(na - nb) < thr;
+    }
+    const unsigned long long bal = __ballot(c);
+    if (threadIdx.x == 0) {
+        bits[(size_t)i * words_cap + blockIdx.x] = bal;
+        if (bal) atomicAdd(&ncons[i], __popcll(bal));  // row sum == column sum (symmetric matrix)
+    }
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#define DPP_MAX(ctrl, rmask) v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false))
+    DPP_MAX(0x111, 0xf); DPP_MAX(0x112, 0xf); DPP_MAX(0x114, 0xf); DPP_MAX(0x118, 0xf);
+    DPP_MAX(0x142, 0xa); DPP_MAX(0x143, 0xc);
+#undef DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int wave_sum_i32_dpp(int v)
+{
+    // inclusive DPP scan inside each row, then carry rows: lanes without a source add 0
+#define DPP_ADD(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
+    DPP_ADD(0x111, 0xf); DPP_ADD(0x112, 0xf); DPP_ADD(0x114, 0xf); DPP_ADD(0x118, 0xf);
+    DPP_ADD(0x142, 0xa); DPP_ADD(0x143, 0xc);
+#undef DPP_ADD
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// greedy clique on one wave over the bit matrix, then ordered compaction of the kept pairs.
+// 32-bit argmax keys ((value + m) << 16 | (0xFFFF - index)) need m < 32768.
+__global__ void __launch_bounds__(64) k_pose_clique(const unsigned long long* __restrict__ bits, int words_cap,
+                                                    const int* __restrict__ ncons, const int* __restrict__ m_dev, int use_filter,
+                                                    const float* __restrict__ pa, const float* __restrict__ pb,
+                                                    float* __restrict__ qa, float* __restrict__ qb, int* __restrict__ n1_out,
+                                                    int lds_m_cap, size_t lds_bits_cap)
+{
+    extern __shared__ int s_mem[];   // 4 * lds_m_cap ints, then lds_bits_cap bytes for the bit matrix
+    const int m = *m_dev;
+    int* clique = s_mem;
+    int* compat = s_mem + lds_m_cap;
+    int* dots = s_mem + 2 * lds_m_cap;
+    int* nc = s_mem + 3 * lds_m_cap;
+    const int lane = threadIdx.x;
+    constexpr int KREG = 8;
+    const int mw0 = (m + 63) >> 6;
+    if (use_filter && m > 0 && m <= 64 * KREG && lds_bits_cap >= (size_t)m * mw0 * 8) {
+        // register-resident variant (m <= 512): lane holds elements j = lane + 64 k; clique /
+        // compatible sets are K-bit masks, the running dot products live in registers and a row of
+        // the bit matrix is K wave-uniform LDS words.
+        unsigned long long* lb = (unsigned long long*)(s_mem + 4 * lds_m_cap);
+        for (int k = lane; k < m * mw0; k += 64) lb[k] = bits[(size_t)(k / mw0) * words_cap + (k % mw0)];
+        __builtin_amdgcn_wave_barrier();
+        int nc_r[KREG], dots_r[KREG];
+        unsigned cl = 0, cp = 0, vmask = 0;
+        unsigned key = 0;
+#pragma unroll
+        for (int k = 0; k < KREG; k++) {
+            const int j = lane + 64 * k;
+            const bool valid = j < m;
+            vmask |= (unsigned)valid << k;
+            nc_r[k] = valid ? ncons[j] : 0;
+            if (valid) key = max(key, ((unsigned)(nc_r[k] + m) << 16) | (unsigned)(0xFFFF - j));
+        }
+        const int seed = 0xFFFF - (int)(wave_max_u32(key) & 0xFFFFu);
+        {
+            const unsigned long long* row = lb + (size_t)seed * mw0;
+#pragma unroll
+            for (int k = 0; k < KREG; k++) {
+                const int b = ((vmask >> k) & 1u) ? (int)((row[k < mw0 ? k : 0] >> lane) & 1ull) : 0;
+                dots_r[k] = b;
+                cp |= (unsigned)b << k;
+            }
+            if (lane == (seed & 63)) cl = 1u << (seed >> 6);
+        }
+        int csize = 1;
+        for (int it = 0; it < m; it++) {
+            int psum = 0;
+            key = 0;
+#pragma unroll
+            for (int k = 0; k < KREG; k++) {
+                if ((vmask >> k) & 1u) {
+                    const int cand = (int)((cp >> k) & 1u) - (int)((cl >> k) & 1u);
+                    psum += cand;
+                    key = max(key, ((unsigned)(nc_r[k] * cand + m) << 16) | (unsigned)(0xFFFF - (lane + 64 * k)));
+                }
+            }
+            psum = wave_sum_i32_dpp(psum);
+            if (psum == 0) break;
+            const int sel = 0xFFFF - (int)(wave_max_u32(key) & 0xFFFFu);
+            const int selk = sel >> 6, sell = sel & 63;
+            const bool mine = lane == sell && ((cl >> selk) & 1u);
+            if (__ballot(mine) == 0ull) {   // sel not yet in the clique
+                csize++;
+                const unsigned long long* row = lb + (size_t)sel * mw0;
+#pragma unroll
+                for (int k = 0; k < KREG; k++)
+                    if ((vmask >> k) & 1u) dots_r[k] += (int)((row[k < mw0 ? k : 0] >> lane) & 1ull);
+                if (lane == sell) cl |= 1u << selk;
+            }
+            cp = 0;
+#pragma unroll
+            for (int k = 0; k < KREG; k++) cp |= (unsigned)(((vmask >> k) & 1u) && dots_r[k] >= csize) << k;
+        }
+#pragma unroll
+        for (int k = 0; k < KREG; k++)
+            if ((vmask >> k) & 1u) clique[lane + 64 * k] = (int)((cl >> k) & 1u);
+        __builtin_amdgcn_wave_barrier();
+    } else if (use_filter && m > 0) {
+        for (int j = lane; j < m; j += 64) nc[j] = ncons[j];
+        // the greedy loop is a chain of dependent row reads: keep the bit matrix in LDS when it fits
+        const int mw = (m + 63) >> 6;
+        const unsigned long long* rows = bits;
+        int rstride = words_cap;
+        if (lds_bits_cap >= (size_t)m * mw * 8) {
+            unsigned long long* lb = (unsigned long long*)(s_mem + 4 * lds_m_cap);
+            for (int k = lane; k < m * mw; k += 64) lb[k] = bits[(size_t)(k / mw) * words_cap + (k % mw)];
+            __builtin_amdgcn_wave_barrier();
+            rows = lb; rstride = mw;
+        }
+        auto bit = [&](int row, int j) -> int { return (int)((rows[(size_t)row * rstride + (j >> 6)] >> (j & 63)) & 1ull); };
+        unsigned key = 0;
+        for (int j = lane; j < m; j += 64) key = max(key, ((unsigned)(nc[j] + m) << 16) | (unsigned)(0xFFFF - j));
+        const int seed = 0xFFFF - (int)(wave_max_u32(key) & 0xFFFFu);
+        for (int j = lane; j < m; j += 64) {
+            const int b = bit(seed, j);
+            clique[j] = j == seed; compat[j] = b; dots[j] = b;
+        }
+        int csize = 1;
+        for (int it = 0; it < m; it++) {
+            int psum = 0;
+            key = 0;
+            for (int j = lane; j < m; j += 64) {
+                const int cand = compat[j] - clique[j];
+                psum += cand;
+                key = max(key, ((unsigned)(nc[j] * cand + m) << 16) | (unsigned)(0xFFFF - j));
+            }
+            psum = wave_sum_i32_dpp(psum);
+            if (psum == 0) break;
+            const int sel = 0xFFFF - (int)(wave_max_u32(key) & 0xFFFFu);
+            const bool fresh = clique[sel] == 0;
+            __builtin_amdgcn_wave_barrier();
+            if (fresh) {
+                csize++;
+                for (int j = lane; j < m; j += 64) dots[j] += bit(sel, j);
+                if (lane == 0) clique[sel] = 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int j = lane; j < m; j += 64) compat[j] = dots[j] >= csize;
+        }
+    }
+    // ordered compaction
+    int base = 0;
+    for (int j0 = 0; j0 < m; j0 += 64) {
+        const int j = j0 + lane;
+        const bool keep = j < m && (!use_filter || clique[j] > 0);
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+            const int o = base + __popcll(bal & ((1ull << lane) - 1ull));
+            for (int c = 0; c < 3; c++) { qa[3 * o + c] = pa[3 * j + c]; qb[3 * o + c] = pb[3 * j + c]; }
+        }
+        base += __popcll(bal);
+    }
+    if (lane == 0) *n1_out = base;
+}
+
+__device__ void dev_cross3(const double* a, const double* b, double* c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// the same one-sided Jacobi SVD as host_svd3, on one device thread
+__device__ void dev_svd3(const double* A, double* U, double* w, double* Vt)
+{
+    double G[9], V[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    for (int k = 0; k < 9; k++) G[k] = A[k];
+    for (int sweep = 0; sweep < 60; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double al = 0, be = 0, ga = 0;
+                for (int i = 0; i < 3; i++) {
+                    al += G[i * 3 + p] * G[i * 3 + p];
+                    be += G[i * 3 + q] * G[i * 3 + q];
+                    ga += G[i * 3 + p] * G[i * 3 + q];
+                }
+                if (fabs(ga) <= 1e-300 || fabs(ga) <= 2.2204460492503131e-16 * sqrt(al * be)) continue;
+                rotated = true;
+                double zeta = (be - al) / (2.0 * ga);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < 3; i++) {
+                    double gp = G[i * 3 + p], gq = G[i * 3 + q];
+                    G[i * 3 + p] = c * gp - s * gq;
+                    G[i * 3 + q] = s * gp + c * gq;
+                    double vp = V[i * 3 + p], vq = V[i * 3 + q];
+                    V[i * 3 + p] = c * vp - s * vq;
+                    V[i * 3 + q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sv[3];
+    int ord[3] = { 0, 1, 2 };
+    for (int j = 0; j < 3; j++) sv[j] = sqrt(G[j] * G[j] + G[3 + j] * G[3 + j] + G[6 + j] * G[6 + j]);
+    for (int i = 0; i < 2; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (sv[ord[j]] > sv[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    double Uc[3][3], Vc[3][3];
+    for (int j = 0; j < 3; j++) {
+        const int o = ord[j];
+        w[j] = sv[o];
+        for (int i = 0; i < 3; i++) {
+            Vc[j][i] = V[i * 3 + o];
+            Uc[j][i] = sv[o] > 0 ? G[i * 3 + o] / sv[o] : 0.0;
+        }
+    }
+    const double tiny = w[0] * 1e-300 + 1e-300;
+    if (w[1] <= tiny) {
+        double a[3] = { 1, 0, 0 };
+        if (fabs(Uc[0][0]) > 0.9) { a[0] = 0; a[1] = 1; }
+        dev_cross3(Uc[0], a, Uc[1]);
+        double nn = sqrt(Uc[1][0] * Uc[1][0] + Uc[1][1] * Uc[1][1] + Uc[1][2] * Uc[1][2]);
+        for (int i = 0; i < 3; i++) Uc[1][i] /= nn;
+    }
+    if (w[2] <= tiny || w[2] <= 1e-14 * w[0]) {
+        dev_cross3(Uc[0], Uc[1], Uc[2]);
+        double nn = sqrt(Uc[2][0] * Uc[2][0] + Uc[2][1] * Uc[2][1] + Uc[2][2] * Uc[2][2]);
+        if (nn > 0) for (int i = 0; i < 3; i++) Uc[2][i] /= nn;
+    }
+    for (int j = 0; j < 3; j++)
+        for (int i = 0; i < 3; i++) { U[i * 3 + j] = Uc[j][i]; Vt[j * 3 + i] = Vc[j][i]; }
+}
+
+__device__ double dev_det3(const double* m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// block-wide float64 sums of up to NV values per thread; result valid in thread 0's copy via sh
+template <int NV>
+__device__ void block_sum_f64(double* a, double (*sh)[16])
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int c = 0; c < NV; c++) { double s = wave_sum_f64(a[c]); if (lane == 0) sh[c][wv] = s; }
+    __syncthreads();
+    for (int c = 0; c < NV; c++) {
+        double s = 0;
+        for (int k = 0; k < nw; k++) s += sh[c][k];
+        a[c] = s;
+    }
+    __syncthreads();
+}
+
+// Umeyama fit of n (device count) pairs in one block: out T[12], scale, rc
+__device__ void dev_umeyama_block(const float* __restrict__ src, const float* __restrict__ dst, int n, int min_n,
+                                  double* T, double* scale, int* rc, double (*sh)[16])
+{
+    if (n < min_n || n < 3) { if (threadIdx.x == 0) *rc = n < 3 ? -1 : 1; return; }   // 1 = not attempted
+    double a[10];
+    for (int c = 0; c < 10; c++) a[c] = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        for (int c = 0; c < 3; c++) { a[c] += (double)src[3 * i + c]; a[3 + c] += (double)dst[3 * i + c]; }
+    block_sum_f64<6>(a, sh);
+    const double inv = 1.0 / n;
+    double ms[3], md[3];
+    for (int c = 0; c < 3; c++) { ms[c] = a[c] * inv; md[c] = a[3 + c] * inv; }
+    for (int c = 0; c < 10; c++) a[c] = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double s[3], d[3];
+        for (int c = 0; c < 3; c++) { s[c] = (double)src[3 * i + c] - ms[c]; d[c] = (double)dst[3 * i + c] - md[c]; }
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) a[r * 3 + c] += d[r] * s[c];
+        a[9] += s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
+    }
+    block_sum_f64<10>(a, sh);
+    if (threadIdx.x == 0) {
+        double cov[9], U[9], w[3], Vt[9];
+        for (int k = 0; k < 9; k++) cov[k] = a[k] * inv;
+        dev_svd3(cov, U, w, Vt);
+        const int nz = (w[0] != 0) + (w[1] != 0) + (w[2] != 0);
+        if (nz < 2) { *rc = -2; }
+        else {
+            double S[3] = { 1, 1, 1 };
+            if (dev_det3(U) * dev_det3(Vt) < 0) S[2] = -1;
+            double R[9];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) {
+                    double acc = 0;
+                    for (int k = 0; k < 3; k++) acc += U[r * 3 + k] * S[k] * Vt[k * 3 + c];
+                    R[r * 3 + c] = acc;
+                }
+            const double sc = (w[0] * S[0] + w[1] * S[1] + w[2] * S[2]) * ((double)n / a[9]);
+            for (int r = 0; r < 3; r++) {
+                double nt = 0;
+                for (int c = 0; c < 3; c++) { T[r * 4 + c] = R[r * 3 + c]; nt += R[r * 3 + c] * ms[c]; }
+                T[r * 4 + 3] = md[r] - sc * nt;
+            }
+            *scale = sc;
+            *rc = 0;
+        }
+    }
+    __syncthreads();
+}
+
+// first fit + single-pass outlier rejection [reference :188-197] + final fit [:204], one block.
+// errs: scratch of capacity >= n1 doubles; qa/qb are compacted in place.
+__global__ void __launch_bounds__(1024) k_pose_fit(float* __restrict__ qa, float* __restrict__ qb, double outlier_thr, int min_matches,
+                                                   double* __restrict__ errs, float* __restrict__ ra, float* __restrict__ rb,
+                                                   PoseOut* __restrict__ out)
+{
+    __shared__ double sh[10][16];
+    __shared__ double s_T[12], s_scale, s_med;
+    __shared__ int s_rc, s_n2, s_nan;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n1 = out->n1;
+    int n2 = n1;
+    const float* fa = qa;
+    const float* fb = qb;
+    if (tid == 0) { s_rc = 1; s_nan = 0; }
+    __syncthreads();
+    if (outlier_thr > 0 && n1 >= 10) {
+        dev_umeyama_block(qa, qb, n1, 3, s_T, &s_scale, &s_rc, sh);
+        if (tid == 0) { out->rc1 = s_rc; for (int k = 0; k < 12; k++) out->T1[k] = s_T[k]; out->s1 = s_scale; }
+        __syncthreads();
+        if (s_rc == 0) {
+            // relative residual on homogeneous 4-vectors
+            for (int i = tid; i < n1; i += nt) {
+                const double x = qa[3 * i], y = qa[3 * i + 1], z = qa[3 * i + 2];
+                const double X = qb[3 * i], Y = qb[3 * i + 1], Z = qb[3 * i + 2];
+                double r[4];
+                for (int k = 0; k < 3; k++) r[k] = ((s_T[k * 4] * x + s_T[k * 4 + 1] * y) + s_T[k * 4 + 2] * z) + s_T[k * 4 + 3];
+                const double dx = X - r[0], dy = Y - r[1], dz = Z - r[2], dw = 1.0 - (((0.0 * x + 0.0 * y) + 0.0 * z) + 1.0);
+                const double e = sqrt(((dx * dx + dy * dy) + dz * dz) + dw * dw) / sqrt(((X * X + Y * Y) + Z * Z) + 1.0);
+                errs[i] = e;
+                if (e != e) s_nan = 1;
+            }
+            __syncthreads();
+            // np.median: mean of the two middle order statistics (NaN if any NaN)
+            if (tid == 0) s_med = 0;
+            __syncthreads();
+            if (!s_nan) {
+                const int k_hi = n1 / 2, k_lo = (n1 - 1) / 2;
+                for (int i = tid; i < n1; i += nt) {
+                    const double e = errs[i];
+                    int rank = 0;
+                    for (int j = 0; j < n1; j++) { const double f = errs[j]; rank += (f < e) || (f == e && j < i); }
+                    if (rank == k_hi) atomicAdd(&s_med, 0.5 * e);
+                    if (rank == k_lo) atomicAdd(&s_med, 0.5 * e);
+                }
+            }
+            __syncthreads();
+            const double thrv = s_nan ? __builtin_nan("") : outlier_thr + s_med;
+            // ordered compaction of errors < threshold into ra/rb
+            if (tid == 0) s_n2 = 0;
+            __syncthreads();
+            if (tid < 64) {
+                int base = 0;
+                for (int j0 = 0; j0 < n1; j0 += 64) {
+                    const int j = j0 + tid;
+                    const bool keep = j < n1 && errs[j] < thrv;
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep) {
+                        const int o = base + __popcll(bal & ((1ull << tid) - 1ull));
+                        for (int c = 0; c < 3; c++) { ra[3 * o + c] = qa[3 * j + c]; rb[3 * o + c] = qb[3 * j + c]; }
+                    }
+                    base += __popcll(bal);
+                }
+                if (tid == 0) s_n2 = base;
+            }
+            __syncthreads();
+            n2 = s_n2;
+            fa = ra; fb = rb;
+        }
+    }
+    if (tid == 0) { out->n2 = n2; if (s_nan) out->flags |= 2; s_rc = 1; }
+    __syncthreads();
+    if (n2 >= min_matches) {
+        dev_umeyama_block(fa, fb, n2, 3, s_T, &s_scale, &s_rc, sh);
+        if (tid == 0) { out->rc2 = s_rc; for (int k = 0; k < 12; k++) out->T2[k] = s_T[k]; out->s2 = s_scale; }
+    } else if (tid == 0)
+        out->rc2 = 1;
+}
+
+__global__ void k_pose_init(PoseOut* out, const int* __restrict__ m_dev, int* __restrict__ flags_dev)
+{
+    out->M = *m_dev; out->n1 = 0; out->n2 = 0; out->flags = 0; out->rc1 = 1; out->rc2 = 1;
+    *flags_dev = 0;
+}
+__global__ void k_pose_flags(PoseOut* out, const int* __restrict__ flags_dev) { out->flags |= *flags_dev; }
+
+extern "C" int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int min_matches, double rigidity_thr,
+                            double outlier_thr, int32_t* counts4 /*M,n1,n2,flags*/, int32_t* rc2 /*first,final*/,
+                            double* T1_12, double* T2_12)
+{
+    if (!ctx || slot_a < 0 || slot_a >= VO_NUM_SLOTS || slot_b < 0 || slot_b >= VO_NUM_SLOTS || !counts4 || !rc2 || !T2_12)
+        return vo_fail(ctx, VO_E_ARG, "vo_pose_pair: bad argument");
+    FrameSlot& a = ctx->slots[slot_a];
+    FrameSlot& b = ctx->slots[slot_b];
+    if (!a.has_kp || !b.has_kp || !a.has_disp || !b.has_disp) return vo_fail(ctx, VO_E_STATE, "slots need disparity and keypoints");
+    if (!ctx->has_Q) return vo_fail(ctx, VO_E_STATE, "vo_set_Q has not been called");
+    counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
+    rc2[0] = rc2[1] = 1;
+    if (a.n_kp == 0) return VO_OK;
+    if (b.n_kp < 2) return vo_fail(ctx, VO_E_ARG, "train set has fewer than 2 descriptors (reference raises IndexError)");
+    const int nq = a.n_kp;
+    if (nq >= 32768 || (size_t)nq * 16 > 60 * 1024) return vo_fail(ctx, VO_E_CAP, "%d query keypoints exceed the fused pose path", nq);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    // workspace: bit matrix + ncons + filtered point sets + residuals + result
+    const int words = (nq + 63) / 64;
+    const size_t need = (size_t)nq * words * 8 + (size_t)nq * 4 + (size_t)nq * 12 * 4 + (size_t)nq * 8 + 4096;
+    if (ctx->clique_ws_bytes < need) {
+        if (ctx->clique_ws) (void)hipFree(ctx->clique_ws);
+        ctx->clique_ws = nullptr; ctx->clique_ws_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->clique_ws, need));
+        ctx->clique_ws_bytes = need;
+    }
+    uint8_t* wsp = ctx->clique_ws;
+    PoseOut* d_out = (PoseOut*)wsp; wsp += 1024;
+    int* d_flags = (int*)wsp; wsp += 256;
+    unsigned long long* d_bits = (unsigned long long*)wsp; wsp += (size_t)nq * words * 8;
+    double* d_errs = (double*)wsp; wsp += (size_t)nq * 8;
+    int* d_ncons = (int*)wsp; wsp += (size_t)nq * 4;
+    float* d_qa = (float*)wsp; wsp += (size_t)nq * 12;
+    float* d_qb = (float*)wsp; wsp += (size_t)nq * 12;
+    float* d_ra = (float*)wsp; wsp += (size_t)nq * 12;
+    float* d_rb = (float*)wsp;
+    int* d_m = ctx->counters;  // k_ratio_compact writes M here
+    int rc;
+    {
+        StageTimer t(ctx, VO_T_MATCH);
+        rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->m_idx, ctx->m_dist);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(64), 0, ctx->stream, ctx->m_idx, ctx->m_dist, a.n_kp, ratio, a.kp_xy,
+                           b.kp_xy, ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, d_m);
+        VO_CHECK_LAUNCH(ctx);
+    }
+    {
+        StageTimer t(ctx, VO_T_POSE);
+        hipLaunchKernelGGL(k_pose_init, dim3(1), dim3(1), 0, ctx->stream, d_out, d_m, d_flags);
+        int x0 = 0, y0 = 0, x1 = a.w, y1 = a.h;
+        if (ctx->has_roi) { x0 = ctx->roi[0]; y0 = ctx->roi[1]; x1 = ctx->roi[2] < a.w ? ctx->roi[2] : a.w; y1 = ctx->roi[3] < a.h ? ctx->roi[3] : a.h; }
+        TapDisp ta{ a.disp16, a.w, x0, y0, make_q(ctx->Q) };
+        TapDisp tb{ b.disp16, b.w, x0, y0, make_q(ctx->Q) };
+        hipLaunchKernelGGL(k_points3d_dev, dim3(div_up(nq, 64)), dim3(64), 0, ctx->stream, ta, x1 - x0, y1 - y0, ctx->xy_a, d_m, ctx->pts_a, ctx->st_a, d_flags);
+        hipLaunchKernelGGL(k_points3d_dev, dim3(div_up(nq, 64)), dim3(64), 0, ctx->stream, tb, x1 - x0, y1 - y0, ctx->xy_b, d_m, ctx->pts_b, ctx->st_b, d_flags);
+        const int use_filter = rigidity_thr > 0;
+        if (use_filter) {
+            VO_HIP(ctx, hipMemsetAsync(d_ncons, 0, (size_t)nq * 4, ctx->stream));
+            hipLaunchKernelGGL(k_pose_cons_bits, dim3(words, nq), dim3(64), 0, ctx->stream, ctx->pts_a, ctx->pts_b, d_m, (float)rigidity_thr,
+                               d_bits, words, d_ncons);
+        }
+        // LDS: 3 int arrays of nq (rounded to even so the bit matrix stays 8-byte aligned) + bit matrix if <= 48 KB
+        const int m_cap = (nq + 1) & ~1;
+        size_t bits_cap = (size_t)nq * words * 8;
+        if ((size_t)m_cap * 16 + bits_cap > 60 * 1024) bits_cap = 0;
+        hipLaunchKernelGGL(k_pose_clique, dim3(1), dim3(64), (size_t)m_cap * 16 + bits_cap, ctx->stream, d_bits, words, d_ncons, d_m,
+                           use_filter, ctx->pts_a, ctx->pts_b, d_qa, d_qb, &d_out->n1, m_cap, bits_cap);
+        hipLaunchKernelGGL(k_pose_flags, dim3(1), dim3(1), 0, ctx->stream, d_out, d_flags);
+        hipLaunchKernelGGL(k_pose_fit, dim3(1), dim3(1024), 0, ctx->stream, d_qa, d_qb, outlier_thr, min_matches, d_errs, d_ra, d_rb, d_out);
+        VO_CHECK_LAUNCH(ctx);
+        VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_out, sizeof(PoseOut), hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = xfer_flush(ctx))) return rc;
+    }
+    const PoseOut* o = (const PoseOut*)ctx->pinned;
+    counts4[0] = o->M; counts4[1] = o->n1; counts4[2] = o->n2; counts4[3] = o->flags;
+    rc2[0] = o->rc1; rc2[1] = o->rc2;
+    if (T1_12) memcpy(T1_12, o->T1, sizeof(o->T1));
+    memcpy(T2_12, o->T2, sizeof(o->T2));
+    return VO_OK;
+}

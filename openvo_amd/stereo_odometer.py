@@ -112,12 +112,45 @@ class StereoOdometer:
         self.save_frame_update(next_img, next_disp, next_3d, next_kps, next_desc)
         return True
 
+    _SEAMS = ("point_clouds", "point_cloud_transform", "rigid_body_filter", "bilinear_interpolate_pixels",
+              "_estimate", "_gate")
+
     def _try_pair(self, kps_a, desc_a, im3d_a, kps_b, desc_b, im3d_b):
+        # fused device path when nothing along the way was replaced by the user
+        if (type(self) is StereoOdometer and type(self.matcher) is BFMatcher and len(kps_b) >= 2
+                and self._on_device(kps_a, desc_a, im3d_a) and self._on_device(kps_b, desc_b, im3d_b)
+                and not any(n in self.__dict__ for n in self._SEAMS)):
+            return self._pair_fused(kps_a.frame.slot, kps_b.frame.slot)
         pts_a, pts_b = self.point_clouds(kps_a, kps_b, desc_a, desc_b, im3d_a, im3d_b)
         if pts_a is None:
             self.skip_cause = "matches"
             return None
         return self.point_cloud_transform(pts_a, pts_b)
+
+    def _pair_fused(self, slot_a, slot_b):
+        """point_clouds + point_cloud_transform in one native call (one device synchronisation);
+        same decisions and skip_cause strings as the two methods."""
+        from ._native import VoError
+        counts, rc, _, T34 = self._ctx.pose_pair(slot_a, slot_b, self.match_threshold, self.min_matches,
+                                                 max(self.rigidity_threshold, 0), max(self.outlier_threshold, 0))
+        M, n1, n2, flags = (int(v) for v in counts)
+        if M < self.min_matches:
+            self.skip_cause = "matches"
+            return None
+        if flags & 1:
+            raise ZeroDivisionError("division by zero")
+        too_few_rigid = n1 < 10
+        if too_few_rigid:
+            self.skip_cause = "rigidity"
+        if rc[0] < 0:
+            raise VoError(-5, "Points cannot be colinear" if rc[0] == -2 else "Umeyama needs at least 3 points")
+        if n2 < self.min_matches:
+            if not too_few_rigid:
+                self.skip_cause = "outlier"
+            return None
+        if rc[1] < 0:
+            raise VoError(-5, "Points cannot be colinear" if rc[1] == -2 else "Umeyama needs at least 3 points")
+        return self._gate(np.vstack([T34, [0, 0, 0, 1]]))
 
     # ------------------------------------------------------------------------------------------
     def point_clouds(self, kps1, kps2, desc1, desc2, im3d1, im3d2):
@@ -171,7 +204,10 @@ class StereoOdometer:
             if not too_few_rigid:
                 self.skip_cause = "outlier"
             return None
-        T = self._estimate(current_pts, next_pts)
+        return self._gate(self._estimate(current_pts, next_pts))
+
+    def _gate(self, T):
+        """NaN check and the motion gates of the reference [:207-223]."""
         if np.isnan(T).any():
             self.skip_cause = "nan"
             return None

@@ -146,3 +146,20 @@ def test_full_size_properties(name, mode, nfeat):
     assert ((dd[xy[:, 1], xy[:, 0]] >= 4) & (dd[xy[:, 1], xy[:, 0]] <= 100)).all()   # mask respected
     idx, dist = cam._ctx.bf_knn2(odo.current_desc, odo.current_desc)
     assert (idx[:, 0] == np.arange(len(kps))).all() and (dist[:, 0] == 0).all()       # self-match
+
+
+@pytest.mark.parametrize("kw", [dict(rigidity_threshold=0.1, outlier_threshold=0.02), dict(outlier_threshold=0.05),
+                                dict(rigidity_threshold=0.02), dict()])
+def test_fused_pair_step_equals_public_seams(kw):
+    """The one-call device path (vo_pose_pair) and the step-by-step public methods give the same
+    decisions and the same pose (tolerance 1e-10: float64 reductions differ in order)."""
+    class Generic(StereoOdometer):     # a subclass never takes the fused shortcut
+        pass
+    c, cam = _rig("C1", max_keypoints=500)
+    fused = StereoOdometer(cam, preprocessed_frames=True, **kw)
+    plain = Generic(cam, preprocessed_frames=True, **kw)
+    for k in range(8):
+        L, R = c.pair(k)
+        a, b = fused.update(L, R), plain.update(L, R)
+        assert a == b and fused.skip_cause == plain.skip_cause and fused.skipped_frames == plain.skipped_frames, k
+        assert np.allclose(fused.c_T_w, plain.c_T_w, rtol=0, atol=1e-10), k
