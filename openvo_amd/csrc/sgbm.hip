@@ -197,6 +197,123 @@ __global__ void __launch_bounds__(256) k_sgbm_cost(const uint32_t* __restrict__ 
     }
 }
 
+// Sweep formulation of the same cost volume.  A wave (64 disparity pairs) walks a strip of XT
+// columns of one image row left to right.  At column x lane l needs the right-image planes at
+// position x - minD - 2l, i.e. what lane l-1 held two columns earlier: the six plane registers
+// live in two lane-shift chains (even / odd columns) advanced by one DPP wave_shr, lane 0 loading
+// the entering element (one broadcast load instead of a 64-lane strided gather).  The horizontal
+// window slides in registers, the vertical window through a 5-row LDS ring per (column, lane) and
+// a register accumulator per column, so C is the only volume written and nothing is re-read.
+__device__ __forceinline__ uint32_t bt_regs(uint32_t lw0, uint32_t lw1, const uint32_t* V)
+{
+    uint32_t acc = 0;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const uint32_t lw = c ? lw1 : lw0;
+        const uint32_t U = pk_rep(lw & 255), U0 = pk_rep((lw >> 8) & 255), U1 = pk_rep((lw >> 16) & 255);
+        const uint32_t c0 = pk_max(pk_max(pk_sub(U, V[c * 3 + 2]), pk_sub(V[c * 3 + 1], U)), 0u);
+        const uint32_t c1 = pk_max(pk_max(pk_sub(V[c * 3 + 0], U1), pk_sub(U0, V[c * 3 + 0])), 0u);
+        uint32_t m = pk_min(c0, c1);
+        if (c == 1) m = (m >> 2) & 0x3FFF3FFFu;
+        acc = pk_add(acc, m);
+    }
+    return acc;
+}
+
+template <int XT>
+__global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR,
+                                                        SgbmGeom g, int TY, int16_t* __restrict__ C)
+{
+    constexpr int SW2 = 2, WIN = 5, NC = XT + 2 * SW2;
+    extern __shared__ uint32_t s_ring[];  // [waves][WIN][XT][64]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int dpl = threadIdx.x;                  // disparity pair index (padded layout)
+    const bool pad = 2 * dpl >= g.D;
+    const int xa = blockIdx.x * XT, ya = blockIdx.y * TY;
+    const size_t plane = (size_t)g.W * g.H;
+    uint32_t* ring = s_ring + (size_t)wv * WIN * XT * 64 + lane;
+    const int yend = min(ya + TY, g.H);
+    const int nrows = (yend - ya) + 2 * SW2;       // rows ya-2 .. yend+1 (clamped)
+    const int lane0_d = 2 * 64 * wv;               // disparity of this wave's lane 0 (relative to minD)
+    // lane i (< NC) fetches, once per row, what column k = i needs: the left-image words and the
+    // element entering the shift chain at lane 0; the columns then pick them up with v_readlane
+    const int krun = min(lane, NC - 1);
+    const int xrun = min(max(xa - SW2 + krun, 0), g.W1 - 1) + g.minX1;
+    const int prun = max(xrun - g.minD - lane0_d, 0);
+    const int pown = max(-g.minD - 2 * (pad ? 0 : dpl), -(1 << 28));   // + ximg = this lane's own position
+
+    uint32_t acc[XT];
+#pragma unroll
+    for (int j = 0; j < XT; j++) acc[j] = pk_rep(g.P2);
+
+    for (int rr = 0; rr < nrows; rr++) {
+        const int r = min(max(ya - SW2 + rr, 0), g.H - 1);
+        const int slot = rr % WIN;
+        const size_t rowi = (size_t)r * g.W;
+        const uint32_t plr0 = PL[(rowi + xrun) * 2], plr1 = PL[(rowi + xrun) * 2 + 1];
+        uint32_t run[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) run[q] = PR[(size_t)q * plane + rowi + prun];
+        uint32_t A[6], B[6];                      // shift chains for even / odd k
+        bool a_init = false, b_init = false;
+        uint32_t pc[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            const int x = xa - SW2 + k;           // block-uniform
+            const int xe = min(max(x, 0), g.W1 - 1);
+            const int ximg = xe + g.minX1;
+            uint32_t* S = (k & 1) ? B : A;
+            bool& inited = (k & 1) ? b_init : a_init;
+            const uint32_t lw0 = (uint32_t)__builtin_amdgcn_readlane((int)plr0, k);
+            const uint32_t lw1 = (uint32_t)__builtin_amdgcn_readlane((int)plr1, k);
+            if (x >= 0 && x < g.W1) {
+                if (!inited) {
+                    // first in-range column of this chain: every lane gathers its own position
+                    const int p = max(ximg + pown, 0);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) S[q] = PR[(size_t)q * plane + rowi + p];
+                    inited = true;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        const uint32_t nv = (uint32_t)__builtin_amdgcn_readlane((int)run[q], k);   // lane 0's new element
+                        S[q] = (uint32_t)__builtin_amdgcn_update_dpp((int)nv, (int)S[q], 0x138, 0xf, 0xf, false);  // wave_shr:1
+                    }
+                }
+                pc[k] = bt_regs(lw0, lw1, S);
+            } else {
+                // replicated border column: same value as the clamped column (direct gather)
+                const int p = max(ximg + pown, 0);
+                uint32_t T[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) T[q] = PR[(size_t)q * plane + rowi + p];
+                pc[k] = bt_regs(lw0, lw1, T);
+            }
+        }
+        // horizontal sliding sums -> vertical ring / accumulators
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < WIN; k++) s = pk_add(s, pc[k]);
+#pragma unroll
+        for (int j = 0; j < XT; j++) {
+            if (j > 0) s = pk_sub(pk_add(s, pc[j + WIN - 1]), pc[j - 1]);
+            uint32_t* cell = ring + (size_t)(slot * XT + j) * 64;
+            if (rr >= WIN) acc[j] = pk_sub(acc[j], *cell);   // the row leaving the window
+            acc[j] = pk_add(acc[j], s);
+            *cell = s;
+        }
+        if (rr >= WIN - 1) {
+            const int y = ya + rr - (WIN - 1);
+#pragma unroll
+            for (int j = 0; j < XT; j++) {
+                const int x1 = xa + j;
+                if (x1 < g.W1 && 2 * dpl < g.Dp)
+                    *(uint32_t*)(C + ((size_t)y * g.W1 + x1) * g.Dp + 2 * dpl) = pad ? MAXC2 : acc[j];
+            }
+        }
+    }
+}
+
 // any block size: direct box sum, one thread per (x1, d pair); slow but exact
 __global__ void k_sgbm_cost_generic(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR,
                                     SgbmGeom g, int16_t* __restrict__ C)
@@ -493,11 +610,24 @@ __device__ __forceinline__ int uf_find(const int* L, int i)
     while (p != i) { i = p; p = L[i]; }
     return i;
 }
+// find with path halving: every write stores an ancestor (a smaller index), so concurrent
+// halving and atomicMin unions cannot create cycles or disconnect a set
+__device__ __forceinline__ int uf_find_halve(int* L, int i)
+{
+    for (;;) {
+        const int p = ((volatile int*)L)[i];
+        if (p == i) return i;
+        const int gp = ((volatile int*)L)[p];
+        if (gp == p) return p;
+        L[i] = gp;
+        i = gp;
+    }
+}
 __device__ __forceinline__ void uf_union(int* L, int a, int b)
 {
     for (int it = 0; it < (1 << 24); it++) {
-        a = uf_find(L, a);
-        b = uf_find(L, b);
+        a = uf_find_halve(L, a);
+        b = uf_find_halve(L, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicMin(&L[a], b);
@@ -565,7 +695,7 @@ __global__ void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int 
 // component sizes: every run head (recognised geometrically -- after unions a head's label may
 // point elsewhere) adds its run length to the component root
 __global__ void k_ccl_sizes(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int maxSize,
-                            const int* __restrict__ L, const int* __restrict__ runlen, int* __restrict__ size)
+                            int* __restrict__ L, const int* __restrict__ runlen, int* __restrict__ size)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
@@ -574,7 +704,8 @@ __global__ void k_ccl_sizes(const int16_t* __restrict__ img, int W, int H, int n
     if (v == newVal) return;
     const bool start = x == 0 || img[i - 1] == newVal || abs(v - img[i - 1]) > maxDiff;
     if (!start) return;
-    const int root = uf_find(L, i);
+    const int root = uf_find_halve(L, i);
+    L[i] = root;   // flatten: k_ccl_apply then needs two hops (pixel -> run head -> root)
     // only "size <= maxSize" is ever asked, and the counter only grows: once it is past the limit
     // further adds are pointless (this removes the contention on the few huge components)
     if (((volatile int*)size)[root] > maxSize) return;
@@ -676,7 +807,17 @@ int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, in
         hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
                            ctx->planesL, ctx->planesR);
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
-        if (g.SW2 == 2) {
+        if (g.SW2 == 2 && ctx->tune_cost_mode == 1) {
+            const int TY = ctx->tune_sweep_ty;
+            const int nw = bx / 64;
+#define LAUNCH_SWEEP(XT)                                                                                               \
+    hipLaunchKernelGGL((k_sgbm_cost_sweep<XT>), dim3(div_up(g.W1, XT), div_up(h, TY)), dim3(bx), (size_t)nw * 5 * XT * 64 * 4, \
+                       ctx->stream, ctx->planesL, ctx->planesR, g, TY, ctx->C)
+            if (ctx->tune_sweep_xt == 8) LAUNCH_SWEEP(8);
+            else if (ctx->tune_sweep_xt == 32) LAUNCH_SWEEP(32);
+            else LAUNCH_SWEEP(16);
+#undef LAUNCH_SWEEP
+        } else if (g.SW2 == 2) {
             const int TY = ctx->tune_cost_ty;
             if (ctx->tune_cost_tx == 4)
                 hipLaunchKernelGGL((k_sgbm_cost<4, 2>), dim3(div_up(g.W1, 4), div_up(h, TY)), dim3(bx), 0, ctx->stream,

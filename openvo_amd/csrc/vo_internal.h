@@ -137,6 +137,7 @@ struct vo_ctx {
 
     // tuning knobs (environment: VO_COST_TX, VO_COST_TY, VO_PATH_PF), read once in vo_create
     int tune_cost_tx = 4, tune_cost_ty = 120, tune_path_pf = 8;
+    int tune_cost_mode = 1, tune_sweep_xt = 8, tune_sweep_ty = 15;   // VO_COST_MODE, VO_SWEEP_XT, VO_SWEEP_TY
 
     // timing
     bool timing = false;
