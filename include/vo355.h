@@ -68,6 +68,10 @@ int vo_upload_pair(vo_ctx* ctx, int slot, const uint8_t* left, const uint8_t* ri
 int vo_stage_pairs_alloc(vo_ctx* ctx, int n, int w, int h, int channels);
 int vo_stage_pair(vo_ctx* ctx, int index, const uint8_t* left, const uint8_t* right);
 int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
+/* look-ahead: ingest + StereoSGBM of staged pair `index` into `slot` on the context's second stream,
+ * asynchronously; later calls that use the slot wait for it on the device.  Lets the next pair's
+ * disparity overlap the current pair's ORB / matching / pose kernels. */
+int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
 /* self.stereoSGBM.compute(L, R) [:51]: int16 disparity x16 of the slot's pair; kept on the
  * device; disp16_out (h*w) may be NULL */
 int vo_sgbm_compute(vo_ctx* ctx, int slot, int16_t* disp16_out);

@@ -20,7 +20,7 @@ T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "
 SYMBOLS = [
     "vo_create", "vo_destroy", "vo_last_error", "vo_device_name", "vo_synchronize",
     "vo_set_rectify_maps", "vo_set_sgbm", "vo_set_Q", "vo_set_roi", "vo_upload_pair",
-    "vo_stage_pairs_alloc", "vo_stage_pair", "vo_load_staged_pair",
+    "vo_stage_pairs_alloc", "vo_stage_pair", "vo_load_staged_pair", "vo_prefetch_staged_pair",
     "vo_sgbm_compute", "vo_sgbm_compute_host", "vo_download_disparity_f32", "vo_download_xyz",
     "vo_download_left", "vo_download_right", "vo_cvt_bgr2gray", "vo_remap", "vo_reproject_to_3d",
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints",
@@ -77,6 +77,7 @@ def lib():
         L.vo_stage_pairs_alloc.argtypes = [vp, ci, ci, ci, ci]
         L.vo_stage_pair.argtypes = [vp, ci, vp, vp]
         L.vo_load_staged_pair.argtypes = [vp, ci, ci, ci]
+        L.vo_prefetch_staged_pair.argtypes = [vp, ci, ci, ci]
         L.vo_sgbm_compute.argtypes = [vp, ci, vp]
         L.vo_sgbm_compute_host.argtypes = [vp, vp, vp, ci, ci, vp]
         for f in (L.vo_download_disparity_f32, L.vo_download_xyz, L.vo_download_left, L.vo_download_right):
@@ -190,6 +191,10 @@ class Context:
 
     def load_staged_pair(self, slot, index, preprocessed):
         self._ck(self._lib.vo_load_staged_pair(self._h, slot, int(index), int(bool(preprocessed))))
+        return self.staged_shape
+
+    def prefetch_staged_pair(self, slot, index, preprocessed):
+        self._ck(self._lib.vo_prefetch_staged_pair(self._h, slot, int(index), int(bool(preprocessed))))
         return self.staged_shape
 
     def sgbm_compute(self, slot, shape=None):

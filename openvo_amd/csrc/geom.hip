@@ -150,6 +150,7 @@ extern "C" int vo_points3d_at(vo_ctx* ctx, int slot, const float* xy, int n, flo
     if (n == 0) return VO_OK;
     if (!xy || !xyz_out || !status_out) return vo_fail(ctx, VO_E_ARG, "vo_points3d_at: null pointer");
     VO_HIP(ctx, hipSetDevice(ctx->device));
+    { int rcw = slot_wait(ctx, f); if (rcw) return rcw; }
     // keypoints must lie inside the cropped image, as img[floor_y, floor_x] requires
     int cw = (ctx->has_roi ? (ctx->roi[2] < f.w ? ctx->roi[2] : f.w) - ctx->roi[0] : f.w);
     int chh = (ctx->has_roi ? (ctx->roi[3] < f.h ? ctx->roi[3] : f.h) - ctx->roi[1] : f.h);
@@ -223,6 +224,7 @@ extern "C" int vo_download_xyz(vo_ctx* ctx, int slot, float* out)
     if (!f.has_disp) return vo_fail(ctx, VO_E_STATE, "slot %d holds no disparity", slot);
     if (!ctx->has_Q) return vo_fail(ctx, VO_E_STATE, "vo_set_Q has not been called");
     VO_HIP(ctx, hipSetDevice(ctx->device));
+    { int rcw = slot_wait(ctx, f); if (rcw) return rcw; }
     const size_t n = (size_t)f.w * f.h;
     int rc = ensure_ws(ctx, &ctx->img3_ws, &ctx->img3_ws_bytes, n * 12);
     if (rc) return rc;
@@ -286,6 +288,7 @@ extern "C" int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio
     FrameSlot& a = ctx->slots[slot_a];
     FrameSlot& b = ctx->slots[slot_b];
     if (!a.has_kp || !b.has_kp || !a.has_disp || !b.has_disp) return vo_fail(ctx, VO_E_STATE, "slots need disparity and keypoints");
+    { int rcw = slot_wait(ctx, a); if (!rcw) rcw = slot_wait(ctx, b); if (rcw) return rcw; }
     *m_out = 0;
     if (a.n_kp == 0) return VO_OK;
     if (b.n_kp < 2) return vo_fail(ctx, VO_E_ARG, "train set has fewer than 2 descriptors (reference raises IndexError)");
@@ -1068,6 +1071,7 @@ extern "C" int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, i
     FrameSlot& a = ctx->slots[slot_a];
     FrameSlot& b = ctx->slots[slot_b];
     if (!a.has_kp || !b.has_kp || !a.has_disp || !b.has_disp) return vo_fail(ctx, VO_E_STATE, "slots need disparity and keypoints");
+    { int rcw = slot_wait(ctx, a); if (!rcw) rcw = slot_wait(ctx, b); if (rcw) return rcw; }
     if (!ctx->has_Q) return vo_fail(ctx, VO_E_STATE, "vo_set_Q has not been called");
     counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
     rc2[0] = rc2[1] = 1;

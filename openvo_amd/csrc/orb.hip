@@ -685,6 +685,7 @@ extern "C" int vo_orb_detect_and_compute(vo_ctx* ctx, int slot, int nfeatures, i
     if (!f.has_pair) return vo_fail(ctx, VO_E_STATE, "slot %d holds no image", slot);
     if (mask_mode == 1 && !f.has_disp) return vo_fail(ctx, VO_E_STATE, "slot %d holds no disparity for the fused mask", slot);
     VO_HIP(ctx, hipSetDevice(ctx->device));
+    { int rcw = slot_wait(ctx, f); if (rcw) return rcw; }
     int x0 = 0, y0 = 0, x1 = f.w, y1 = f.h;
     if (ctx->has_roi) { x0 = ctx->roi[0]; y0 = ctx->roi[1]; x1 = ctx->roi[2] < f.w ? ctx->roi[2] : f.w; y1 = ctx->roi[3] < f.h ? ctx->roi[3] : f.h; }
     const int cw = x1 - x0, ch = y1 - y0;

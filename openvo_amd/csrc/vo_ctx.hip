@@ -114,6 +114,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s)", prop.name, prop.gcnArchName);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
+    if ((e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
 
@@ -123,11 +124,13 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     for (int s = 0; s <= VO_NUM_SLOTS; s++) {
         FrameSlot& f = ctx->slots[s];
         DALLOC(f.left, npx); DALLOC(f.right, npx); DALLOC(f.disp16, npx);
+        (void)hipEventCreateWithFlags(&f.ready, hipEventDisableTiming);
         DALLOC(f.kp_xy, (size_t)ctx->kp_cap * 2); DALLOC(f.kp_size, ctx->kp_cap); DALLOC(f.kp_angle, ctx->kp_cap);
         DALLOC(f.kp_resp, ctx->kp_cap); DALLOC(f.kp_oct, ctx->kp_cap); DALLOC(f.desc, (size_t)ctx->kp_cap * 32);
     }
     ctx->stage_bytes = npx * 3;
     DALLOC(ctx->stage_in, ctx->stage_bytes * 2);
+    DALLOC(ctx->stage_in2, ctx->stage_bytes * 2);
     for (int c = 0; c < 2; c++) { DALLOC(ctx->map1[c], npx * 2); DALLOC(ctx->map2[c], npx); }
     DALLOC(ctx->planesL, npx * 2); DALLOC(ctx->planesR, npx * 6);
     ctx->vol_cells = npx * (size_t)((max_disp + 31) & ~31);
@@ -178,13 +181,15 @@ extern "C" void vo_destroy(vo_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int s = 0; s <= VO_NUM_SLOTS; s++) {
         FrameSlot& f = ctx->slots[s];
         void* ps[] = { f.left, f.right, f.disp16, f.kp_xy, f.kp_size, f.kp_angle, f.kp_resp, f.kp_oct, f.desc };
         for (void* p : ps) if (p) (void)hipFree(p);
+        if (f.ready) (void)hipEventDestroy(f.ready);
     }
-    void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
+    void* ps[] = { ctx->stage_in, ctx->stage_in2, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
                    ctx->C, ctx->S, ctx->disp_raw, ctx->disp_tmp, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->pyr_img, ctx->pyr_blur,
                    ctx->pyr_mask, ctx->pyr_score, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->cand_pos,
                    ctx->cand_resp, ctx->candA_pos, ctx->candA_resp, ctx->candB_pos, ctx->candB_resp, ctx->kp_pos, ctx->pyr_tmp16, ctx->counters, ctx->host_mask_dev, ctx->mq, ctx->mt,
@@ -197,6 +202,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 
@@ -340,6 +346,7 @@ extern "C" int vo_upload_pair(vo_ctx* ctx, int slot, const uint8_t* left, const 
     if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context %dx%d", w, h, ctx->max_w, ctx->max_h);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     FrameSlot& f = ctx->slots[slot];
+    if ((rc = slot_wait(ctx, f))) return rc;
     StageTimer t(ctx, VO_T_UPLOAD);
     // the two cameras use disjoint halves of the staging buffer (4 bytes/pixel each would be
     // needed for colour + gray; stage_in holds 6 bytes/pixel)
@@ -387,11 +394,50 @@ extern "C" int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preproc
     const int w = ctx->staged_w, h = ctx->staged_h;
     const size_t per = (size_t)w * h * ctx->staged_ch;
     StageTimer t(ctx, VO_T_UPLOAD);
+    if ((rc = slot_wait(ctx, f))) return rc;
     rc = ingest(ctx, 0, ctx->staged + per * 2 * index, w, h, ctx->staged_ch, preprocessed, f.left, ctx->stage_in, hipMemcpyDeviceToDevice);
     if (rc) return rc;
     rc = ingest(ctx, 1, ctx->staged + per * (2 * index + 1), w, h, ctx->staged_ch, preprocessed, f.right, ctx->stage_in, hipMemcpyDeviceToDevice);
     if (rc) return rc;
     f.w = w; f.h = h; f.has_pair = true; f.has_disp = false; f.has_kp = false; f.n_kp = 0;
+    return VO_OK;
+}
+
+int slot_wait(vo_ctx* ctx, FrameSlot& f)
+{
+    if (f.pending) {
+        VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, f.ready, 0));
+        f.pending = false;
+    }
+    return VO_OK;
+}
+
+// look-ahead: ingest + SGBM of a staged pair on the second stream.  The main stream keeps running
+// the previous pair's ORB / matching / pose meanwhile; consumers of the slot wait on its event.
+extern "C" int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (index < 0 || index >= ctx->staged_n) return vo_fail(ctx, VO_E_ARG, "vo_prefetch_staged_pair: bad index");
+    if (!ctx->sg.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    FrameSlot& f = ctx->slots[slot];
+    const int w = ctx->staged_w, h = ctx->staged_h;
+    const size_t per = (size_t)w * h * ctx->staged_ch;
+    std::swap(ctx->stream, ctx->stream2);
+    std::swap(ctx->stage_in, ctx->stage_in2);
+    {
+        StageTimer t(ctx, VO_T_UPLOAD);
+        rc = ingest(ctx, 0, ctx->staged + per * 2 * index, w, h, ctx->staged_ch, preprocessed, f.left, ctx->stage_in, hipMemcpyDeviceToDevice);
+        if (!rc) rc = ingest(ctx, 1, ctx->staged + per * (2 * index + 1), w, h, ctx->staged_ch, preprocessed, f.right, ctx->stage_in, hipMemcpyDeviceToDevice);
+    }
+    if (!rc) rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
+    hipError_t e = rc ? hipSuccess : hipEventRecord(f.ready, ctx->stream);
+    std::swap(ctx->stream, ctx->stream2);
+    std::swap(ctx->stage_in, ctx->stage_in2);
+    if (rc) return rc;
+    if (e != hipSuccess) return vo_fail(ctx, VO_E_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+    f.w = w; f.h = h; f.has_pair = true; f.has_disp = true; f.has_kp = false; f.n_kp = 0; f.pending = true;
     return VO_OK;
 }
 
@@ -402,6 +448,7 @@ extern "C" int vo_sgbm_compute(vo_ctx* ctx, int slot, int16_t* disp16_out)
     FrameSlot& f = ctx->slots[slot];
     if (!f.has_pair) return vo_fail(ctx, VO_E_STATE, "slot %d holds no image pair", slot);
     VO_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = slot_wait(ctx, f))) return rc;
     rc = sgbm_run(ctx, f.left, f.right, f.w, f.h, f.disp16);
     if (rc) return rc;
     f.has_disp = true;
@@ -482,6 +529,7 @@ extern "C" int vo_download_disparity_f32(vo_ctx* ctx, int slot, float* out)
     FrameSlot& f = ctx->slots[slot];
     if (!f.has_disp || !out) return vo_fail(ctx, VO_E_STATE, "slot %d holds no disparity", slot);
     VO_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = slot_wait(ctx, f))) return rc;
     const int n = f.w * f.h;
     if ((rc = ensure_img3(ctx, (size_t)n * 12))) return rc;
     hipLaunchKernelGGL(k_disp_to_f32, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, f.disp16, n, ctx->img3_ws);
@@ -498,6 +546,7 @@ extern "C" int vo_download_left(vo_ctx* ctx, int slot, uint8_t* out)
     FrameSlot& f = ctx->slots[slot];
     if (!f.has_pair || !out) return vo_fail(ctx, VO_E_STATE, "slot %d holds no image", slot);
     VO_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = slot_wait(ctx, f))) return rc;
     VO_HIP(ctx, hipMemcpyAsync(out, f.left, (size_t)f.w * f.h, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VO_OK;
@@ -510,6 +559,7 @@ extern "C" int vo_download_right(vo_ctx* ctx, int slot, uint8_t* out)
     FrameSlot& f = ctx->slots[slot];
     if (!f.has_pair || !out) return vo_fail(ctx, VO_E_STATE, "slot %d holds no image", slot);
     VO_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = slot_wait(ctx, f))) return rc;
     VO_HIP(ctx, hipMemcpyAsync(out, f.right, (size_t)f.w * f.h, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VO_OK;

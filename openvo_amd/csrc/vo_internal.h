@@ -39,11 +39,16 @@ struct FrameSlot {
     int n_kp = 0;
     int w = 0, h = 0;
     bool has_pair = false, has_disp = false, has_kp = false;
+    // look-ahead: the pair was ingested + SGBM'd on the second stream; `ready` orders consumers
+    hipEvent_t ready = nullptr;
+    bool pending = false;
 };
 
 struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // look-ahead stream (vo_prefetch_*): next pair's SGBM overlaps this pair's ORB / pose
+    uint8_t* stage_in2 = nullptr;    // staging of the look-ahead stream
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;
     std::string err;
     char devname[256] = {0};
@@ -180,6 +185,9 @@ static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 int xfer_h2d(vo_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
 int xfer_d2h(vo_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
 int xfer_flush(vo_ctx* ctx);
+
+// make the main stream wait for a slot whose look-ahead work may still be running
+int slot_wait(vo_ctx* ctx, FrameSlot& f);
 
 // implemented in the per-stage files
 int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);

@@ -21,6 +21,11 @@ class StagedPair:
         self.index = int(index)
 
 
+def _RESERVED():
+    """Stand-in "owner" of a slot held by look-ahead work (callable like a weakref, never dead)."""
+    return _RESERVED
+
+
 class StereoCamera:
     @classmethod
     def from_pfiles(cls, left_cam_file, right_cam_file, rect_file, sgbm_file, img_size, **kw):
@@ -58,21 +63,37 @@ class StereoCamera:
         self.stereoSGBM = StereoSGBM(self._ctx, sgbm_params)
         self._slot_owner = [None] * _native.VO_NUM_SLOTS   # weak bookkeeping: FrameHandle per slot
         self._next_slot = 0
+        self.lookahead = True        # staged pairs: run pair i+1's SGBM on a second stream during pair i
+        self._lookahead = None       # ((index, preprocessed), slot, (w, h)) of the pair in flight
+        self._n_staged = 0
 
     # ---- slot bookkeeping -------------------------------------------------------------------
     def _release_slot(self, slot, frame):
         if self._slot_owner[slot] is not None and self._slot_owner[slot]() is frame:
             self._slot_owner[slot] = None
 
-    def _acquire_slot(self):
-        import weakref
+    def _free_slot(self):
         n = _native.VO_NUM_SLOTS
         for k in range(n):
             s = (self._next_slot + k) % n
             ref = self._slot_owner[s]
             if ref is None or ref() is None:
                 self._next_slot = (s + 1) % n
-                return s, weakref
+                return s
+        return None
+
+    def _acquire_slot(self):
+        import weakref
+        n = _native.VO_NUM_SLOTS
+        s = self._free_slot()
+        if s is not None:
+            return s, weakref
+        if self._lookahead is not None:
+            # reclaim the slot held by an unconsumed look-ahead before evicting a live frame
+            s = self._lookahead[1]
+            self._lookahead = None
+            self._slot_owner[s] = None
+            return s, weakref
         # every slot is still referenced by user code: move the oldest frame to host memory
         s = self._next_slot
         old = self._slot_owner[s]()
@@ -86,6 +107,8 @@ class StereoCamera:
         """Upload (left, right) pairs once and keep them in HBM; returns StagedPair handles.
         Not in the reference: lets a caller overlap / amortise host-to-device ingest."""
         self._ctx.stage_pairs(pairs)
+        self._lookahead = None
+        self._n_staged = len(pairs)
         return [StagedPair(i) for i in range(len(pairs))]
 
     # ---- reference API ----------------------------------------------------------------------
@@ -121,16 +144,35 @@ class StereoCamera:
                 img_left = self._ctx.cvt_bgr2gray(img_left)
             if img_right.ndim == 3:
                 img_right = self._ctx.cvt_bgr2gray(img_right)
-        slot, weakref = self._acquire_slot()
+        import weakref
+        slot = None
         if staged:
-            w, h = self._ctx.load_staged_pair(slot, img_left.index, preprocessed)
-        else:
-            w, h = self._ctx.upload_pair(slot, img_left, img_right, preprocessed)
-        self._ctx.sgbm_compute(slot)
+            # was this pair already ingested + SGBM'd on the look-ahead stream?
+            hit = self._lookahead
+            self._lookahead = None
+            if hit is not None and hit[0] == (img_left.index, bool(preprocessed)):
+                slot, (w, h) = hit[1], hit[2]
+            elif hit is not None:
+                self._slot_owner[hit[1]] = None          # stale prediction: give the slot back
+        if slot is None:
+            slot, _ = self._acquire_slot()
+            if staged:
+                w, h = self._ctx.load_staged_pair(slot, img_left.index, preprocessed)
+            else:
+                w, h = self._ctx.upload_pair(slot, img_left, img_right, preprocessed)
+            self._ctx.sgbm_compute(slot)
         vr = self.valid_region_left
         # numpy slice semantics (negative / oversized bounds clip)
         y0, y1, _ = slice(vr[1], vr[3]).indices(h)
         x0, x1, _ = slice(vr[0], vr[2]).indices(w)
         frame = FrameHandle(self, slot, w, h, (x0, y0, max(x1, x0), max(y1, y0)))
         self._slot_owner[slot] = weakref.ref(frame)
+        if staged and self.lookahead and img_left.index + 1 < self._n_staged:
+            # start the NEXT staged pair on the second stream: its disparity overlaps this pair's
+            # ORB / matching / pose kernels (only if a slot is free -- never evict for a guess)
+            nxt = self._free_slot()
+            if nxt is not None:
+                shape = self._ctx.prefetch_staged_pair(nxt, img_left.index + 1, preprocessed)
+                self._slot_owner[nxt] = _RESERVED
+                self._lookahead = ((img_left.index + 1, bool(preprocessed)), nxt, shape)
         return DeviceImage(frame, "xyz"), DeviceImage(frame, "disp"), DeviceImage(frame, "left")
