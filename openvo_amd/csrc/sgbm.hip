@@ -616,9 +616,9 @@ __device__ __forceinline__ int uf_find_halve(int* L, int i)
 {
     for (;;) {
         const int p = ((volatile int*)L)[i];
-        if (p == i) return i;
+        if (p == i || p < 0) return i;      // p < 0 cannot happen for a labelled pixel; never index with it
         const int gp = ((volatile int*)L)[p];
-        if (gp == p) return p;
+        if (gp == p || gp < 0) return p;
         L[i] = gp;
         i = gp;
     }
@@ -770,7 +770,23 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
     return VO_OK;
 }
 
+static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);
+
+// The SGBM workspaces (planes, C, L volumes, CCL arrays) are shared by the main and the look-ahead
+// stream: a run on one stream must not start before the previous run -- possibly on the other
+// stream -- has finished.  An event chain orders them on the device without blocking the host.
 int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp)
+{
+    if (ctx->sgbm_done_valid) VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sgbm_done, 0));
+    int rc = sgbm_run_impl(ctx, dL, dR, w, h, d_disp);
+    if (ctx->sgbm_done) {
+        VO_HIP(ctx, hipEventRecord(ctx->sgbm_done, ctx->stream));
+        ctx->sgbm_done_valid = true;
+    }
+    return rc;
+}
+
+static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp)
 {
     const SgbmEff& e = ctx->sg;
     if (!e.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");

@@ -115,6 +115,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s)", prop.name, prop.gcnArchName);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
     if ((e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
+    (void)hipEventCreateWithFlags(&ctx->sgbm_done, hipEventDisableTiming);
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
 
@@ -199,6 +200,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->staged) (void)hipFree(ctx->staged);
+    if (ctx->sgbm_done) (void)hipEventDestroy(ctx->sgbm_done);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

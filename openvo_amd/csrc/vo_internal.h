@@ -49,6 +49,8 @@ struct vo_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // look-ahead stream (vo_prefetch_*): next pair's SGBM overlaps this pair's ORB / pose
     uint8_t* stage_in2 = nullptr;    // staging of the look-ahead stream
+    hipEvent_t sgbm_done = nullptr;  // end of the latest SGBM run on either stream (shared workspaces)
+    bool sgbm_done_valid = false;
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;
     std::string err;
     char devname[256] = {0};

@@ -20,7 +20,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 ODO_KW = dict(nfeatures=500, match_threshold=0.8, rigidity_threshold=0.1, outlier_threshold=0.02,
@@ -79,12 +79,6 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # the interpreter's cyclic GC (a full collection with torch loaded costs ~50 ms) must not fire
-    # inside the timed region: collect now, then keep it off until the clock stops
-    import gc
-    gc.collect()
-    gc.freeze()
-    gc.disable()
     for i in range(W):
         odo.update(staged[i], None)
     # HIP events (recorded on the library's stream, resolved after the run) around the dominant
@@ -94,14 +88,17 @@ def main():
     rel, acc = [], []
     sync_all()
     t0 = time.perf_counter()
+    _ts=[]
     for i in range(W, W + K):
+        _ts.append(time.perf_counter())
         before = odo.c_T_w
         ok = odo.update(staged[i], None)
         acc.append(bool(ok))
         rel.append(sharding.relative_from_chain(before, odo.c_T_w) if ok else np.eye(4))
     sync_all()
     dt = time.perf_counter() - t0
-    gc.enable()
+    _d=np.diff(np.array(_ts))*1e3
+    print('argmax', int(np.argmax(_d)), 'top', np.round(np.sort(_d)[-4:],2), file=sys.stderr); print('steps ms: min %.3f med %.3f mean %.3f max %.3f; first10 %s; last5 %s' % (_d.min(), np.median(_d), _d.mean(), _d.max(), np.round(_d[:10],2), np.round(_d[-5:],2)), file=sys.stderr)
     tm = ctx.timings(reset=True)
     # per-stage breakdown (information only): a short untimed post-pass with every stage timed
     ctx.enable_timing(True)
