@@ -43,10 +43,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
+    use_cuda = True
+    ndev = 0
     if world > 1:
         import torch
         import torch.distributed as dist
-        use_cuda = torch.cuda.is_available()
+        ndev = torch.cuda.device_count()
+        # one GPU per rank -> RCCL ("nccl"); fewer GPUs than ranks (rehearsal on a 1-GPU box) -> ranks
+        # share devices and the tiny pose gather goes over gloo
+        use_cuda = ndev >= world
         if use_cuda:
             torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl" if use_cuda else "gloo", rank=rank, world_size=world)
@@ -64,7 +69,8 @@ def main():
     K, W = args.steps, args.warmup
     c = Corridor(args.workload)
     cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h),
-                       device=local_rank, max_keypoints=ODO_KW["nfeatures"])
+                       device=(local_rank if (world == 1 or use_cuda) else local_rank % max(ndev, 1)),
+                       max_keypoints=ODO_KW["nfeatures"])
     odo = StereoOdometer(cam, **ODO_KW)
     # this rank's frames: W warm-up frames (they also provide the halo) then K timed frames
     first = rank * K
@@ -114,13 +120,13 @@ def main():
 
     # max over ranks of the timed region
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if use_cuda else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_max = float(t.item())
     else:
         dt_max = dt
     # final pose gather (the path's only exchange): 16 float64 + accept flag per frame
-    dev = ("cuda:%d" % local_rank) if (dist is not None and torch.cuda.is_available()) else None
+    dev = ("cuda:%d" % local_rank) if (dist is not None and use_cuda) else None
     all_rel, all_ok = sharding.gather_relative(np.array(rel), np.array(acc, np.float64), dist, dev)
 
     if rank == 0:
