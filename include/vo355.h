@@ -34,7 +34,8 @@ enum {
     VO_E_NUMERIC = -5  /* degenerate input (Umeyama: <3 points / colinear) */
 };
 
-#define VO_NUM_SLOTS 4 /* frame slots per context: the odometer keeps prev, current, next */
+#define VO_NUM_SLOTS 6 /* frame slots per context: the odometer keeps prev, current, next; two more
+                          may hold look-ahead pairs */
 
 /* lifetime ------------------------------------------------------------------------- */
 int vo_create(int device_id, int max_w, int max_h, int max_disp, int max_kp, vo_ctx** out);

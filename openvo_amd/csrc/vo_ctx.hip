@@ -182,6 +182,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int s = 0; s <= VO_NUM_SLOTS; s++) {
@@ -201,6 +202,13 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->staged) (void)hipFree(ctx->staged);
     if (ctx->sgbm_done) (void)hipEventDestroy(ctx->sgbm_done);
+    {
+        vo_ctx::SgbmWs& a = ctx->ws_alt;
+        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.disp_raw, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->stage_in3 };
+        for (void* q : pa) if (q) (void)hipFree(q);
+        if (a.done) (void)hipEventDestroy(a.done);
+        if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -405,6 +413,47 @@ extern "C" int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preproc
     return VO_OK;
 }
 
+// swap the main stream / staging (and for engine 1 the SGBM workspace) with a look-ahead engine's;
+// calling it twice restores the context
+static void engine_swap(vo_ctx* ctx, int engine)
+{
+    if (engine == 0) {
+        std::swap(ctx->stream, ctx->stream2);
+        std::swap(ctx->stage_in, ctx->stage_in2);
+        return;
+    }
+    std::swap(ctx->stream, ctx->stream3);
+    std::swap(ctx->stage_in, ctx->stage_in3);
+    vo_ctx::SgbmWs& a = ctx->ws_alt;
+    std::swap(ctx->planesL, a.planesL); std::swap(ctx->planesR, a.planesR);
+    std::swap(ctx->C, a.C); std::swap(ctx->S, a.S); std::swap(ctx->S_vols, a.S_vols);
+    std::swap(ctx->disp_raw, a.disp_raw); std::swap(ctx->disp_tmp, a.disp_tmp);
+    std::swap(ctx->ccl_runlen, a.ccl_runlen); std::swap(ctx->ccl_label, a.ccl_label); std::swap(ctx->ccl_size, a.ccl_size);
+    std::swap(ctx->sgbm_done, a.done); std::swap(ctx->sgbm_done_valid, a.done_valid);
+}
+
+static int alloc_alt_workspace(vo_ctx* ctx)
+{
+    vo_ctx::SgbmWs& a = ctx->ws_alt;
+    const size_t npx = (size_t)ctx->max_w * ctx->max_h;
+    const int vols = ctx->S_vols > 5 ? ctx->S_vols : 5;
+    VO_HIP(ctx, hipMalloc((void**)&a.planesL, npx * 2 * 4 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&a.planesR, npx * 6 * 4 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&a.C, ctx->vol_cells * 2 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&a.S, ctx->vol_cells * 2 * vols + 256));
+    a.S_vols = vols;
+    VO_HIP(ctx, hipMalloc((void**)&a.disp_raw, npx * 2 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&a.disp_tmp, npx * 2 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&a.ccl_runlen, npx * 4 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&a.ccl_label, npx * 4 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&a.ccl_size, npx * 4 + 256));
+    VO_HIP(ctx, hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+    VO_HIP(ctx, hipMalloc((void**)&ctx->stage_in3, ctx->stage_bytes * 2 + 256));
+    VO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+    ctx->ws_alt_ready = true;
+    return VO_OK;
+}
+
 int slot_wait(vo_ctx* ctx, FrameSlot& f)
 {
     if (f.pending) {
@@ -426,8 +475,13 @@ extern "C" int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int pre
     FrameSlot& f = ctx->slots[slot];
     const int w = ctx->staged_w, h = ctx->staged_h;
     const size_t per = (size_t)w * h * ctx->staged_ch;
-    std::swap(ctx->stream, ctx->stream2);
-    std::swap(ctx->stage_in, ctx->stage_in2);
+    // alternate between the two look-ahead engines
+    const int engine = ctx->next_engine;
+    if (engine == 1 && !ctx->ws_alt_ready) {
+        if ((rc = alloc_alt_workspace(ctx))) return rc;
+    }
+    ctx->next_engine ^= 1;
+    engine_swap(ctx, engine);
     {
         StageTimer t(ctx, VO_T_UPLOAD);
         rc = ingest(ctx, 0, ctx->staged + per * 2 * index, w, h, ctx->staged_ch, preprocessed, f.left, ctx->stage_in, hipMemcpyDeviceToDevice);
@@ -435,8 +489,7 @@ extern "C" int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int pre
     }
     if (!rc) rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
     hipError_t e = rc ? hipSuccess : hipEventRecord(f.ready, ctx->stream);
-    std::swap(ctx->stream, ctx->stream2);
-    std::swap(ctx->stage_in, ctx->stage_in2);
+    engine_swap(ctx, engine);
     if (rc) return rc;
     if (e != hipSuccess) return vo_fail(ctx, VO_E_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
     f.w = w; f.h = h; f.has_pair = true; f.has_disp = true; f.has_kp = false; f.n_kp = 0; f.pending = true;

@@ -49,6 +49,20 @@ struct vo_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // look-ahead stream (vo_prefetch_*): next pair's SGBM overlaps this pair's ORB / pose
     uint8_t* stage_in2 = nullptr;    // staging of the look-ahead stream
+    // second look-ahead engine: its own stream, staging and SGBM workspace, so that two pairs' SGBM
+    // can be in flight (one pair's latency-bound kernels overlap the other's bandwidth-bound ones)
+    hipStream_t stream3 = nullptr;
+    uint8_t* stage_in3 = nullptr;
+    struct SgbmWs {
+        uint32_t *planesL = nullptr, *planesR = nullptr;
+        int16_t *C = nullptr, *S = nullptr, *disp_raw = nullptr, *disp_tmp = nullptr;
+        int32_t *ccl_runlen = nullptr, *ccl_label = nullptr, *ccl_size = nullptr;
+        int S_vols = 0;
+        hipEvent_t done = nullptr;
+        bool done_valid = false;
+    } ws_alt;
+    bool ws_alt_ready = false;
+    int next_engine = 0;
     hipEvent_t sgbm_done = nullptr;  // end of the latest SGBM run on either stream (shared workspaces)
     bool sgbm_done_valid = false;
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;

@@ -63,8 +63,8 @@ class StereoCamera:
         self.stereoSGBM = StereoSGBM(self._ctx, sgbm_params)
         self._slot_owner = [None] * _native.VO_NUM_SLOTS   # weak bookkeeping: FrameHandle per slot
         self._next_slot = 0
-        self.lookahead = True        # staged pairs: run pair i+1's SGBM on a second stream during pair i
-        self._lookahead = None       # ((index, preprocessed), slot, (w, h)) of the pair in flight
+        self.lookahead = 2           # staged pairs: how many following pairs run their SGBM ahead (0, 1 or 2)
+        self._lookahead = []         # [((index, preprocessed), slot, (w, h))] of the pairs in flight
         self._n_staged = 0
 
     # ---- slot bookkeeping -------------------------------------------------------------------
@@ -88,10 +88,9 @@ class StereoCamera:
         s = self._free_slot()
         if s is not None:
             return s, weakref
-        if self._lookahead is not None:
+        if self._lookahead:
             # reclaim the slot held by an unconsumed look-ahead before evicting a live frame
-            s = self._lookahead[1]
-            self._lookahead = None
+            s = self._lookahead.pop()[1]
             self._slot_owner[s] = None
             return s, weakref
         # every slot is still referenced by user code: move the oldest frame to host memory
@@ -107,7 +106,9 @@ class StereoCamera:
         """Upload (left, right) pairs once and keep them in HBM; returns StagedPair handles.
         Not in the reference: lets a caller overlap / amortise host-to-device ingest."""
         self._ctx.stage_pairs(pairs)
-        self._lookahead = None
+        for hit in self._lookahead:
+            self._slot_owner[hit[1]] = None
+        self._lookahead = []
         self._n_staged = len(pairs)
         return [StagedPair(i) for i in range(len(pairs))]
 
@@ -148,11 +149,12 @@ class StereoCamera:
         slot = None
         if staged:
             # was this pair already ingested + SGBM'd on the look-ahead stream?
-            hit = self._lookahead
-            self._lookahead = None
-            if hit is not None and hit[0] == (img_left.index, bool(preprocessed)):
-                slot, (w, h) = hit[1], hit[2]
-            elif hit is not None:
+            key = (img_left.index, bool(preprocessed))
+            while self._lookahead:
+                hit = self._lookahead.pop(0)
+                if hit[0] == key:
+                    slot, (w, h) = hit[1], hit[2]
+                    break
                 self._slot_owner[hit[1]] = None          # stale prediction: give the slot back
         if slot is None:
             slot, _ = self._acquire_slot()
@@ -167,12 +169,17 @@ class StereoCamera:
         x0, x1, _ = slice(vr[0], vr[2]).indices(w)
         frame = FrameHandle(self, slot, w, h, (x0, y0, max(x1, x0), max(y1, y0)))
         self._slot_owner[slot] = weakref.ref(frame)
-        if staged and self.lookahead and img_left.index + 1 < self._n_staged:
-            # start the NEXT staged pair on the second stream: its disparity overlaps this pair's
-            # ORB / matching / pose kernels (only if a slot is free -- never evict for a guess)
-            nxt = self._free_slot()
-            if nxt is not None:
-                shape = self._ctx.prefetch_staged_pair(nxt, img_left.index + 1, preprocessed)
+        if staged and self.lookahead:
+            # start the NEXT staged pairs on the look-ahead streams: their disparity overlaps this
+            # pair's ORB / matching / pose kernels (only into free slots -- never evict for a guess)
+            have = {h[0][0] for h in self._lookahead}
+            for idx in range(img_left.index + 1, min(img_left.index + 1 + int(self.lookahead), self._n_staged)):
+                if idx in have:
+                    continue
+                nxt = self._free_slot()
+                if nxt is None:
+                    break
+                shape = self._ctx.prefetch_staged_pair(nxt, idx, preprocessed)
                 self._slot_owner[nxt] = _RESERVED
-                self._lookahead = ((img_left.index + 1, bool(preprocessed)), nxt, shape)
+                self._lookahead.append(((idx, bool(preprocessed)), nxt, shape))
         return DeviceImage(frame, "xyz"), DeviceImage(frame, "disp"), DeviceImage(frame, "left")
