@@ -163,3 +163,63 @@ def test_fused_pair_step_equals_public_seams(kw):
         a, b = fused.update(L, R), plain.update(L, R)
         assert a == b and fused.skip_cause == plain.skip_cause and fused.skipped_frames == plain.skipped_frames, k
         assert np.allclose(fused.c_T_w, plain.c_T_w, rtol=0, atol=1e-10), k
+
+
+def test_c2_full_size_frame_matches_oracle(oracle):
+    """One BASELINE-size frame (1280x720, D=128) against the oracle: disparity, keypoints,
+    descriptors bit-exact (the oracle needs ~6 s for it)."""
+    c = Corridor("C2")
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=500)
+    L, R = c.pair(9)
+    ref16 = oracle.sgbm_compute(L, R, c.sgbm_params(), 0)
+    assert np.array_equal(cam.stereoSGBM.compute(L, R), ref16)
+    odo = StereoOdometer(cam, preprocessed_frames=True)
+    assert odo.update(L, R)
+    vr = cam.valid_region_left
+    d = (ref16.astype(np.float32) / 16)[vr[1]:vr[3], vr[0]:vr[2]]
+    ref = oracle.orb_detect_and_compute(L[vr[1]:vr[3], vr[0]:vr[2]], odo.feature_mask(d), 500)
+    assert np.array_equal(odo.current_kps.xy.view(np.uint32), ref["xy"].view(np.uint32))
+    assert np.array_equal(odo.current_kps.angle.view(np.uint32), ref["angle"].view(np.uint32))
+    assert np.array_equal(odo.current_desc, ref["desc"])
+
+
+def test_edge_cases_keypoints_and_masks():
+    c, cam = _rig("T0", max_keypoints=300)
+    odo = StereoOdometer(cam, nfeatures=300, preprocessed_frames=True)
+    flat = np.full((c.h, c.w), 90, np.uint8)
+    assert odo.update(flat, flat) is False                     # textureless: no disparity, no keypoints
+    assert odo.skip_cause == "keypoints" and odo.skipped_frames == 1 and odo.current_img is None
+    kps, desc = odo.orb.detectAndCompute(flat, None)
+    assert len(kps) == 0 and desc is None                      # cv2 returns ((), None)
+    L, R = c.pair(0)
+    kps, desc = odo.orb.detectAndCompute(L, np.zeros_like(L))  # everything masked out
+    assert len(kps) == 0 and desc is None
+    kps, desc = odo.orb.detectAndCompute(L[:50, :50].copy(), None)   # smaller than the 31-px border on each side
+    assert len(kps) == 0 and desc is None
+    idx, dist = cam._ctx.bf_knn2(np.zeros((3, 32), np.uint8), np.zeros((1, 32), np.uint8))
+    assert idx.tolist() == [[0, -1]] * 3                       # fewer than k train rows
+    with pytest.raises(IndexError):
+        cam._ctx.ratio_filter(idx, dist, 0.8)                  # what m[1] raises in the reference
+    # all-inf taps raise ZeroDivisionError like the reference's bilinear_interpolate_pixels
+    img = np.full((4, 4, 3), np.inf, np.float32)
+    with pytest.raises(ZeroDivisionError):
+        odo.bilinear_interpolate_pixels(img, 1.5, 1.5)
+    # min_matches larger than the number of keypoints -> "keypoints"; then recovers
+    odo2 = StereoOdometer(cam, nfeatures=300, preprocessed_frames=True, min_matches=100000)
+    assert odo2.update(L, R) is False and odo2.skip_cause == "keypoints"
+
+
+def test_context_argument_errors():
+    from openvo_amd import _native
+    with pytest.raises(_native.VoError):
+        _native.Context(0, 32, 32, 16, 64)                     # below the minimum size
+    ctx = _native.Context(0, 128, 128, 32, 64)
+    with pytest.raises(_native.VoError):
+        ctx.set_sgbm(dict(minDisparity=0, numDisparities=40, blockSize=5, P1=8, P2=32, disp12MaxDiff=1, preFilterCap=31,
+                          uniquenessRatio=10, speckleWindowSize=0, speckleRange=0))      # not a multiple of 16
+    with pytest.raises(_native.VoError):
+        ctx.set_sgbm(dict(minDisparity=0, numDisparities=64, blockSize=5, P1=8, P2=32, disp12MaxDiff=1, preFilterCap=31,
+                          uniquenessRatio=10, speckleWindowSize=0, speckleRange=0))      # exceeds max_disp
+    with pytest.raises(_native.VoError):
+        ctx.sgbm_compute_host(np.zeros((256, 256), np.uint8), np.zeros((256, 256), np.uint8))   # exceeds max size
+    ctx.close()
