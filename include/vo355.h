@@ -154,6 +154,16 @@ int vo_rigid_clique(vo_ctx* ctx, const float* prev, const float* cur, int m, dou
 /* cv2.Rodrigues(R)[0] [:212]; host only */
 int vo_rodrigues(const double* R9, double* r3);
 
+/* RANSAC essential-matrix hypothesis scoring (BASELINE config 5) -------------------------------
+ * NOT part of the reference (openVO has no RANSAC): defined by this build.  iters
+ * hypotheses from 8-point minimal sets drawn by a counter-based hash RNG (seed), Sampson distance
+ * (pixels, float32) against thr, inliers counted with wavefront ballot + popcount.  pts: n x 2
+ * float32 pixel coordinates; K4 = fx, fy, cx, cy.  best2 = {winning hypothesis, its inlier count}
+ * (ties -> lowest hypothesis index); mask_out (n) and counts_out (iters) may be NULL. */
+int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K4, int iters,
+                        float thr, uint32_t seed, double* E9_out, uint8_t* mask_out, int32_t* counts_out,
+                        int32_t* best2_out);
+
 /* instrumentation ------------------------------------------------------------------------ */
 /* hipEvent timing of the kernels launched on the context stream (events are recorded without
  * blocking and resolved by vo_get_timings).  Stage ids: */

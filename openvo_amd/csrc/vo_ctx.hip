@@ -196,7 +196,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
                    ctx->pyr_mask, ctx->pyr_score, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->cand_pos,
                    ctx->cand_resp, ctx->candA_pos, ctx->candA_resp, ctx->candB_pos, ctx->candB_resp, ctx->kp_pos, ctx->pyr_tmp16, ctx->counters, ctx->host_mask_dev, ctx->mq, ctx->mt,
                    ctx->m_idx, ctx->m_dist, ctx->pts_a, ctx->pts_b, ctx->st_a, ctx->st_b, ctx->xy_a, ctx->xy_b,
-                   ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws };
+                   ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws, ctx->ransac_ws };
     for (void* p : ps) if (p) (void)hipFree(p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);

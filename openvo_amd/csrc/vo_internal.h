@@ -144,6 +144,8 @@ struct vo_ctx {
     double* red = nullptr;         // reduction scratch
     uint8_t* clique_ws = nullptr;
     size_t clique_ws_bytes = 0;
+    uint8_t* ransac_ws = nullptr;
+    size_t ransac_ws_bytes = 0;
     float* img3_ws = nullptr;
     size_t img3_ws_bytes = 0;
     void* pinned = nullptr;        // pinned host buffer: first 4 KB scalar readbacks, rest = transfer arena

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libvo_oracle.so")
-_SRC = ["src/sgbm.c", "src/imgproc.c", "src/orb.c", "src/match.c", "src/geom.c", "vo_oracle.h"]
+_SRC = ["src/sgbm.c", "src/imgproc.c", "src/orb.c", "src/match.c", "src/geom.c", "src/ransac.c", "vo_oracle.h"]
 
 
 def build_oracle(force=False):
@@ -228,3 +228,20 @@ def svd3(A):
     U, w, Vt = np.empty((3, 3)), np.empty(3), np.empty((3, 3))
     lib().vo_ref_svd3(_p(A), _p(U), _p(w), _p(Vt))
     return U, w, Vt
+
+
+def ransac_essential(p1, p2, K4, iters=5000, thr=1.0, seed=4321):
+    """-> dict(E 3x3, mask uint8 n, counts int32 iters, best_iter, best_count)"""
+    p1, p2, K4 = _c(p1, np.float32).reshape(-1, 2), _c(p2, np.float32).reshape(-1, 2), _c(K4, np.float64)
+    n = len(p1)
+    E = np.zeros(9, np.float64)
+    mask = np.zeros(n, np.uint8)
+    counts = np.zeros(iters, np.int32)
+    bi = ctypes.c_int(-1)
+    f = lib().vo_ref_ransac_essential
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                  ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    best = f(_p(p1), _p(p2), n, _p(K4), int(iters), float(thr), int(seed), _p(E), _p(mask), _p(counts), ctypes.byref(bi))
+    if best < 0:
+        raise ValueError("ransac_essential needs at least 8 correspondences")
+    return dict(E=E.reshape(3, 3), mask=mask, counts=counts, best_iter=bi.value, best_count=best)

@@ -104,6 +104,14 @@ void vo_ref_rodrigues(const double* R9, double* r3);
 void vo_ref_rigid_clique(const float* prev, const float* cur, int m, double thr, int64_t* mask);
 void vo_ref_svd3(const double* A9, double* U9, double* w3, double* Vt9);
 
+/* ---- RANSAC essential-matrix hypothesis scoring (BASELINE config 5; no openVO counterpart) ---- */
+void vo_ref_ransac_sample8(uint32_t seed, int h, int n, int* idx8);
+void vo_ref_essential_8pt(const float* p1, const float* p2, const int* idx8, const double* K4 /*fx fy cx cy*/, double* E9);
+void vo_ref_fundamental_f32(const double* E9, const double* K4, float* F9);
+int vo_ref_sampson_count(const float* F9, const float* p1, const float* p2, int n, float thr, uint8_t* mask);
+int vo_ref_ransac_essential(const float* p1, const float* p2, int n, const double* K4, int iters, float thr,
+                            uint32_t seed, double* E_best9, uint8_t* mask, int32_t* counts, int* best_iter);
+
 #ifdef __cplusplus
 }
 #endif

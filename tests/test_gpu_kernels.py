@@ -126,3 +126,39 @@ def test_rigid_clique_matches_reference_golden(ctx_small):
             b = k[:-5]
             m = ctx_small.rigid_clique(g3[b + "_prev"], g3[b + "_cur"], float(g3[b + "_thr"]))
             assert np.array_equal(m, g3[k]), b
+
+
+def _two_view(n, seed, outlier_frac=0.25):
+    rng = np.random.default_rng(seed)
+    f, cx, cy = 1050.0, 960.0, 540.0
+    X = np.c_[rng.uniform(-8, 8, n), rng.uniform(-4, 4, n), rng.uniform(6, 40, n)]
+    ang = 0.03
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([0.05, 0.01, -0.25])
+    X2 = X @ R.T + t
+    p1 = np.c_[f * X[:, 0] / X[:, 2] + cx, f * X[:, 1] / X[:, 2] + cy] + rng.normal(scale=0.3, size=(n, 2))
+    p2 = np.c_[f * X2[:, 0] / X2[:, 2] + cx, f * X2[:, 1] / X2[:, 2] + cy] + rng.normal(scale=0.3, size=(n, 2))
+    out = rng.choice(n, int(n * outlier_frac), replace=False)
+    p2[out] += rng.uniform(-80, 80, size=(len(out), 2))
+    return p1.astype(np.float32), p2.astype(np.float32), [f, f, cx, cy], R, t, out
+
+
+@pytest.mark.parametrize("n,iters", [(2000, 500), (8, 16), (8000, 300), (77, 1000)])
+def test_ransac_essential_bit_exact(oracle, ctx_small, n, iters):
+    """No openVO counterpart: GPU vs the build's own CPU restatement -- every hypothesis' inlier
+    count, the winner, its mask and E identical (E to 1e-12: same operations, both IEEE)."""
+    p1, p2, K4, R, t, out = _two_view(n, n + iters)
+    ref = oracle.ransac_essential(p1, p2, K4, iters, 1.0, 4321)
+    got = ctx_small.ransac_essential(p1, p2, K4, iters, 1.0, 4321, want_counts=True)
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert got["best_iter"] == ref["best_iter"] and got["best_count"] == ref["best_count"]
+    assert np.array_equal(got["mask"], ref["mask"])
+    assert np.allclose(got["E"], ref["E"], rtol=0, atol=1e-12)
+    if n >= 2000:
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Et = tx @ R
+        Et /= np.linalg.norm(Et)
+        E = got["E"] / np.linalg.norm(got["E"])
+        assert min(np.abs(E - Et).max(), np.abs(E + Et).max()) < 0.06   # sanity of the estimator, not a parity bar
+        inl = np.setdiff1d(np.arange(n), out)
+        assert got["mask"][inl].mean() > 0.95 and got["mask"][out].mean() < 0.1
