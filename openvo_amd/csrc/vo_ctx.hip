@@ -226,6 +226,8 @@ extern "C" int vo_device_name(const vo_ctx* ctx, char* buf, int buflen)
 extern "C" int vo_synchronize(vo_ctx* ctx)
 {
     if (!ctx) return VO_E_ARG;
+    if (ctx->stream3) VO_HIP(ctx, hipStreamSynchronize(ctx->stream3));
+    if (ctx->stream2) VO_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }

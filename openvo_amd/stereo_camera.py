@@ -112,6 +112,14 @@ class StereoCamera:
         self._n_staged = len(pairs)
         return [StagedPair(i) for i in range(len(pairs))]
 
+    def reset_lookahead(self):
+        """Drop look-ahead work that has been started but not consumed (its slots are released and
+        the pairs will be recomputed when asked for)."""
+        self._ctx.synchronize()
+        for hit in self._lookahead:
+            self._slot_owner[hit[1]] = None
+        self._lookahead = []
+
     # ---- reference API ----------------------------------------------------------------------
     def undistort_rectify_left(self, img):
         return self._rectify(0, img)

@@ -117,7 +117,7 @@ class StereoOdometer:
 
     def _try_pair(self, kps_a, desc_a, im3d_a, kps_b, desc_b, im3d_b):
         # fused device path when nothing along the way was replaced by the user
-        if (type(self) is StereoOdometer and type(self.matcher) is BFMatcher and len(kps_b) >= 2
+        if (type(self) is StereoOdometer and type(self.matcher) is BFMatcher and 2 <= len(kps_b) and len(kps_a) <= 3800
                 and self._on_device(kps_a, desc_a, im3d_a) and self._on_device(kps_b, desc_b, im3d_b)
                 and not any(n in self.__dict__ for n in self._SEAMS)):
             return self._pair_fused(kps_a.frame.slot, kps_b.frame.slot)

@@ -45,6 +45,7 @@ def _load():
 CONFIGS = {
     "C1": (640, 480, 400.0, 320.0, 240.0, 0.12, 3.0, 60.0, 64),
     "C2": (1280, 720, 718.856, 640.0, 360.0, 0.537, 6.0, 400.0, 128),
+    "C5": (1920, 1080, 1050.0, 960.0, 540.0, 0.537, 6.0, 400.0, 16),   # monocular: left images only
     "C4": (2048, 1536, 1400.0, 1024.0, 768.0, 0.537, 6.0, 400.0, 256),
     # reduced shape used by fast CPU tests (not a BASELINE config)
     "T0": (320, 240, 200.0, 160.0, 120.0, 0.25, 3.0, 60.0, 32),
