@@ -10,8 +10,9 @@
 //   L[dir][y][x1][Dp]    int16    : one aggregated volume per path direction
 // Kernels
 //   k_sgbm_planes  prefilter + Birchfield-Tomasi half-pixel bounds (elementwise)
-//   k_sgbm_cost    BT pixel cost + (2*SW2+1)^2 box sum; one lane = one disparity PAIR in packed
-//                  int16x2 math, sliding sums in registers; writes C once
+//   k_sgbm_cost_sweep  BT pixel cost + (2*SW2+1)^2 box sum; one lane = one disparity PAIR in packed
+//                  int16x2 math; right-image planes travel through DPP lane-shift chains, the horizontal
+//                  window slides in registers, the vertical one through an LDS ring; writes C once
 //   k_sgbm_paths   ALL path directions in one launch.  A scan line lives in one 16-lane DPP row
 //                  (each lane holds Dp/16 consecutive disparities in packed registers), so a wave
 //                  advances 4 independent lines; neighbours d-1/d+1 come from row_shr/row_shl
@@ -126,77 +127,6 @@ __device__ __forceinline__ uint32_t bt_pair(const uint32_t* __restrict__ PL, con
     return acc;
 }
 
-// tile TX columns x TY rows per wave-row of lanes.  Horizontal window via a register sliding sum
-// over the TX+2*SW2 evaluated columns, vertical window via a register ring.
-template <int TX, int SW2>
-__global__ void __launch_bounds__(256) k_sgbm_cost(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR,
-                                                  SgbmGeom g, int TY, int16_t* __restrict__ C)
-{
-    constexpr int WIN = 2 * SW2 + 1;
-    const int dpl = threadIdx.x;  // disparity pair index in the padded layout
-    if (2 * dpl >= g.Dp) return;
-    const bool pad = 2 * dpl >= g.D;
-    const int dp = pad ? 0 : dpl;  // pad lanes compute a valid pair and store the sentinel instead
-    const int xa = blockIdx.x * TX, ya = blockIdx.y * TY;
-    const size_t plane = (size_t)g.W * g.H;
-    const int pbase = g.minX1 - g.minD - 2 * dp;  // right position = x1 + pbase
-
-    uint32_t ring[TX][WIN];
-    uint32_t acc[TX];
-#pragma unroll
-    for (int j = 0; j < TX; j++) acc[j] = pk_rep(g.P2);
-
-    auto row_hsum = [&](int r, uint32_t* hs) {
-        uint32_t pc[TX + 2 * SW2];
-#pragma unroll
-        for (int k = 0; k < TX + 2 * SW2; k++) {
-            int xe = min(max(xa - SW2 + k, 0), g.W1 - 1);
-            pc[k] = bt_pair(PL, PR, plane, g.W, r, xe + g.minX1, xe + pbase);
-        }
-        uint32_t s = 0;
-#pragma unroll
-        for (int k = 0; k < WIN; k++) s = pk_add(s, pc[k]);
-        hs[0] = s;
-#pragma unroll
-        for (int j = 1; j < TX; j++) {
-            s = pk_sub(pk_add(s, pc[j + WIN - 1]), pc[j - 1]);
-            hs[j] = s;
-        }
-    };
-
-#pragma unroll
-    for (int k = 0; k < WIN; k++) {
-        uint32_t hs[TX];
-        row_hsum(min(max(ya - SW2 + k, 0), g.H - 1), hs);
-#pragma unroll
-        for (int j = 0; j < TX; j++) { ring[j][k] = hs[j]; acc[j] = pk_add(acc[j], hs[j]); }
-    }
-    const int yend = min(ya + TY, g.H);
-    for (int y0 = ya; y0 < yend; y0 += WIN) {
-#pragma unroll
-        for (int k = 0; k < WIN; k++) {
-            const int y = y0 + k;
-            if (y < yend) {
-#pragma unroll
-                for (int j = 0; j < TX; j++) {
-                    int x1 = xa + j;
-                    if (x1 < g.W1)
-                        *(uint32_t*)(C + ((size_t)y * g.W1 + x1) * g.Dp + 2 * dpl) = pad ? MAXC2 : acc[j];
-                }
-                if (y + 1 < yend) {
-                    uint32_t hs[TX];
-                    row_hsum(min(y + 1 + SW2, g.H - 1), hs);
-#pragma unroll
-                    for (int j = 0; j < TX; j++) {
-                        acc[j] = pk_sub(pk_add(acc[j], hs[j]), ring[j][k]);
-                        ring[j][k] = hs[j];
-                    }
-                }
-            }
-        }
-    }
-}
-
 // Sweep formulation of the same cost volume.  A wave (64 disparity pairs) walks a strip of XT
 // columns of one image row left to right.  At column x lane l needs the right-image planes at
 // position x - minD - 2l, i.e. what lane l-1 held two columns earlier: the six plane registers
@@ -220,11 +150,11 @@ __device__ __forceinline__ uint32_t bt_regs(uint32_t lw0, uint32_t lw1, const ui
     return acc;
 }
 
-template <int XT>
+template <int XT, int SW2>
 __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR,
                                                         SgbmGeom g, int TY, int16_t* __restrict__ C)
 {
-    constexpr int SW2 = 2, WIN = 5, NC = XT + 2 * SW2;
+    constexpr int WIN = 2 * SW2 + 1, NC = XT + 2 * SW2;
     extern __shared__ uint32_t s_ring[];  // [waves][WIN][XT][64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int dpl = threadIdx.x;                  // disparity pair index (padded layout)
@@ -823,27 +753,22 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
         hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
                            ctx->planesL, ctx->planesR);
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
-        if (g.SW2 == 2 && ctx->tune_cost_mode == 1) {
-            const int TY = ctx->tune_sweep_ty;
-            const int nw = bx / 64;
-#define LAUNCH_SWEEP(XT)                                                                                               \
-    hipLaunchKernelGGL((k_sgbm_cost_sweep<XT>), dim3(div_up(g.W1, XT), div_up(h, TY)), dim3(bx), (size_t)nw * 5 * XT * 64 * 4, \
-                       ctx->stream, ctx->planesL, ctx->planesR, g, TY, ctx->C)
-            if (ctx->tune_sweep_xt == 8) LAUNCH_SWEEP(8);
-            else if (ctx->tune_sweep_xt == 32) LAUNCH_SWEEP(32);
-            else LAUNCH_SWEEP(16);
-#undef LAUNCH_SWEEP
-        } else if (g.SW2 == 2) {
-            const int TY = ctx->tune_cost_ty;
-            if (ctx->tune_cost_tx == 4)
-                hipLaunchKernelGGL((k_sgbm_cost<4, 2>), dim3(div_up(g.W1, 4), div_up(h, TY)), dim3(bx), 0, ctx->stream,
-                                   ctx->planesL, ctx->planesR, g, TY, ctx->C);
-            else
-                hipLaunchKernelGGL((k_sgbm_cost<8, 2>), dim3(div_up(g.W1, 8), div_up(h, TY)), dim3(bx), 0, ctx->stream,
-                                   ctx->planesL, ctx->planesR, g, TY, ctx->C);
-        } else {
-            hipLaunchKernelGGL(k_sgbm_cost_generic, dim3(g.W1, h), dim3(bx), 0, ctx->stream, ctx->planesL, ctx->planesR, g, ctx->C);
+        const int TY = ctx->tune_sweep_ty;
+        const int nw = bx / 64;
+#define LAUNCH_SWEEP(XT, SW)                                                                                                   \
+    hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(div_up(g.W1, XT), div_up(h, TY)), dim3(bx),                            \
+                       (size_t)nw * (2 * SW + 1) * XT * 64 * 4, ctx->stream, ctx->planesL, ctx->planesR, g, TY, ctx->C)
+        switch (g.SW2) {
+            case 0: LAUNCH_SWEEP(8, 0); break;
+            case 1: LAUNCH_SWEEP(8, 1); break;
+            case 2: if (ctx->tune_sweep_xt == 16) LAUNCH_SWEEP(16, 2); else LAUNCH_SWEEP(8, 2); break;
+            case 3: LAUNCH_SWEEP(8, 3); break;
+            case 4: LAUNCH_SWEEP(8, 4); break;
+            case 5: LAUNCH_SWEEP(8, 5); break;
+            default:
+                hipLaunchKernelGGL(k_sgbm_cost_generic, dim3(g.W1, h), dim3(bx), 0, ctx->stream, ctx->planesL, ctx->planesR, g, ctx->C);
         }
+#undef LAUNCH_SWEEP
         VO_CHECK_LAUNCH(ctx);
     }
     int rc;

@@ -168,11 +168,8 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         g_create_err = "hipHostMalloc failed"; vo_destroy(ctx); return VO_E_HIP;
     }
-    if (const char* e1 = getenv("VO_COST_TX")) ctx->tune_cost_tx = atoi(e1) == 4 ? 4 : 8;
-    if (const char* e2 = getenv("VO_COST_TY")) { int v = atoi(e2); if (v >= 5 && v <= 2000) ctx->tune_cost_ty = (v / 5) * 5; }
     if (const char* e3 = getenv("VO_PATH_PF")) { int v = atoi(e3); if (v == 2 || v == 4 || v == 8) ctx->tune_path_pf = v; }
-    if (const char* e4 = getenv("VO_COST_MODE")) ctx->tune_cost_mode = atoi(e4) ? 1 : 0;
-    if (const char* e5 = getenv("VO_SWEEP_XT")) { int v = atoi(e5); if (v == 8 || v == 16 || v == 32) ctx->tune_sweep_xt = v; }
+    if (const char* e5 = getenv("VO_SWEEP_XT")) { int v = atoi(e5); if (v == 8 || v == 16) ctx->tune_sweep_xt = v; }
     if (const char* e6 = getenv("VO_SWEEP_TY")) { int v = atoi(e6); if (v >= 4 && v <= 4096) ctx->tune_sweep_ty = v; }
     *out = ctx;
     return VO_OK;

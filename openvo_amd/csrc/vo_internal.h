@@ -158,9 +158,8 @@ struct vo_ctx {
     uint8_t* staged = nullptr;
     int staged_n = 0, staged_w = 0, staged_h = 0, staged_ch = 1;
 
-    // tuning knobs (environment: VO_COST_TX, VO_COST_TY, VO_PATH_PF), read once in vo_create
-    int tune_cost_tx = 4, tune_cost_ty = 120, tune_path_pf = 8;
-    int tune_cost_mode = 1, tune_sweep_xt = 8, tune_sweep_ty = 15;   // VO_COST_MODE, VO_SWEEP_XT, VO_SWEEP_TY
+    // tuning knobs (environment: VO_PATH_PF, VO_SWEEP_XT, VO_SWEEP_TY), read once in vo_create
+    int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 15;
 
     // timing
     bool timing = false;
