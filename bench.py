@@ -135,7 +135,7 @@ def main():
         value = total_pairs / dt_max
         cells, npaths = ctx.sgbm_last_geometry()
         agg_ms, agg_n = tm["sgbm_agg"]
-        n_launch = agg_n                                               # one k_sgbm_paths launch per pair (all directions)
+        n_launch = agg_n                                               # one k_sgbm_paths launch per pair
         per_launch_s = (agg_ms / 1e3) / max(n_launch, 1)
         alg_bytes = 2.0 * cells * npaths                               # the int16 cost volume read once per path direction
         achieved = alg_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
@@ -155,7 +155,7 @@ def main():
                                    "Hamming kNN/ratio + 3-D lookup + rigid clique + Umeyama" % (args.workload, c.w, c.h, c.D, ODO_KW["nfeatures"]),
                        "odometer": {k: ODO_KW[k] for k in ("rigidity_threshold", "outlier_threshold", "match_threshold", "min_matches")},
                        "parallelism": "frame-sharded x%d, pose all_gather" % world, "inputs": "resident in HBM"},
-            "roofline": {"bound": "hbm", "kernel": "k_sgbm_paths (all %d aggregation directions in one launch)" % npaths,
+            "roofline": {"bound": "hbm", "kernel": "k_sgbm_paths (%d aggregation directions in one launch; the last one runs fused with the WTA)" % npaths,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "bytes_per_launch": alg_bytes, "launch_us": round(per_launch_s * 1e6, 2), "launches": n_launch},

@@ -34,7 +34,7 @@ enum {
     VO_E_NUMERIC = -5  /* degenerate input (Umeyama: <3 points / colinear) */
 };
 
-#define VO_NUM_SLOTS 6 /* frame slots per context: the odometer keeps prev, current, next; two more
+#define VO_NUM_SLOTS 7 /* frame slots per context: the odometer keeps prev, current, next; two more
                           may hold look-ahead pairs */
 
 /* lifetime ------------------------------------------------------------------------- */
@@ -173,8 +173,9 @@ enum { VO_T_UPLOAD = 0, VO_T_SGBM_COST, VO_T_SGBM_AGG, VO_T_SGBM_WTA, VO_T_SGBM_
 int vo_enable_timing(vo_ctx* ctx, int on);
 /* accumulated milliseconds and launch counts per stage since the last reset */
 int vo_get_timings(vo_ctx* ctx, double* ms_out /*VO_T_NSTAGES*/, int64_t* launches_out, int reset);
-/* algorithmic cost-volume cells (width1*H*D) of the last vo_sgbm_compute, and number of
- * aggregation-path launches it made */
+/* algorithmic cost-volume cells (width1*H*D) of the last vo_sgbm_compute, and the number of path
+ * directions aggregated inside its k_sgbm_paths launch (the remaining top-down vertical direction
+ * runs fused with the WTA) */
 int vo_sgbm_last_geometry(vo_ctx* ctx, int64_t* cells, int* n_paths);
 
 #ifdef __cplusplus

@@ -25,6 +25,7 @@
 #include "vo_internal.h"
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 #define MAXC 0x7FFF
 #define MAXC2 0x7FFF7FFFu
@@ -37,6 +38,10 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u(as_s(a) + as_s(b)); }
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u(as_s(a) - as_s(b)); }
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_add_sat(as_s(a), as_s(b))); }
+__device__ __forceinline__ uint32_t pk_sub_sat_u(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
 __device__ __forceinline__ uint32_t pk_rep(int v) { return (uint32_t)(v & 0xFFFF) * 0x00010001u; }
 
 #define DPP(old, src, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, 0xf, 0xf, false))
@@ -45,12 +50,13 @@ __device__ __forceinline__ uint32_t pk_rep(int v) { return (uint32_t)(v & 0xFFFF
 #define ROW_ROR(n) (0x120 + (n))
 
 // all-reduce (min, unsigned) inside each 16-lane row: every lane ends with the row minimum
+// (old = the identity of min lets the compiler fold each rotate into one v_min_u32_dpp)
 __device__ __forceinline__ uint32_t row_min_u32(uint32_t v)
 {
-    v = min(v, DPP(v, v, ROW_ROR(8)));
-    v = min(v, DPP(v, v, ROW_ROR(4)));
-    v = min(v, DPP(v, v, ROW_ROR(2)));
-    v = min(v, DPP(v, v, ROW_ROR(1)));
+    v = min(v, DPP(0xFFFFFFFFu, v, ROW_ROR(8)));
+    v = min(v, DPP(0xFFFFFFFFu, v, ROW_ROR(4)));
+    v = min(v, DPP(0xFFFFFFFFu, v, ROW_ROR(2)));
+    v = min(v, DPP(0xFFFFFFFFu, v, ROW_ROR(1)));
     return v;
 }
 
@@ -417,6 +423,132 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
 // ---------------------------------------------------------------------------------------
 // winner-take-all: 16 lanes per pixel
 // ---------------------------------------------------------------------------------------
+// winner of one pixel's summed costs: lowest S (first d on ties) and the uniqueness verdict, per 16-lane row.
+// THR (needs uniquenessRatio < 100): the uniqueness test S*(100-ur) < minS*100 is rewritten as
+// S < T = ceil(minS*100 / (100-ur)) (all operands non-negative integers) and evaluated on packed
+// halves with no branches; the generic form keeps OpenCV's products.
+template <int NP, bool PAD, bool THR>
+__device__ __forceinline__ void wta_core(const LV<NP>& S, const SgbmGeom& g, int lane, int& minS, int& best, bool& row_viol)
+{
+    const int l16 = lane & 15, d0 = l16 * 2 * NP;
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const int d = d0 + 2 * k;
+        if (!PAD || d < g.D) {
+            const uint32_t k0 = ((S.r[k] & 0xFFFFu) << 8) | (uint32_t)d;
+            const uint32_t k1 = ((S.r[k] >> 16) << 8) | (uint32_t)(d + 1);
+            key = min(key, min(k0, k1));
+        }
+    }
+    key = row_min_u32(key);
+    minS = (int)(key >> 8);
+    best = (int)(key & 255u);
+    bool viol = false;
+    const int ur100 = 100 - g.ur;
+    if (THR) {
+        // exact ceil(minS*100 / ur100): float estimate (operands < 2^24) + integer fix-up
+        const int a = minS * 100;
+        int T = (int)((float)a * __builtin_amdgcn_rcpf((float)ur100));
+        T += (T * ur100 < a);
+        T += (T * ur100 < a);
+        T -= ((T - 1) * ur100 >= a);
+        T -= ((T - 1) * ur100 >= a);
+        const uint32_t T2 = pk_rep(min(T, 32768));   // S <= 32767: a larger T changes nothing
+        // bit e of m8: this lane's element e (d = d0 + e) lies within one of the winner -- never a violation
+        const int t = min(max(best + 4 - d0, 0), 31);
+        uint32_t m8 = ((7u << t) >> 5) & ((1u << (2 * NP)) - 1u);   // 2NP <= 16 elements per lane
+        if (PAD) {
+            const int npad = min(max(d0 + 2 * NP - g.D, 0), 2 * NP);   // trailing elements beyond D
+            m8 |= (0xFFFFu << (2 * NP - npad)) & ((1u << (2 * NP)) - 1u);
+        }
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * k, 1);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * k + 1, 1);
+            const uint32_t excl = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
+            any |= pk_sub_sat_u(T2, S.r[k]) & ~excl;   // a non-zero half: S < T
+        }
+        viol = any != 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int d = d0 + 2 * k;
+            if (!PAD || d < g.D) {
+                const int s0 = (int)(S.r[k] & 0xFFFFu), s1 = (int)(S.r[k] >> 16);
+                viol |= (s0 * ur100 < minS * 100) && (abs(best - d) > 1);
+                viol |= (s1 * ur100 < minS * 100) && (abs(best - d - 1) > 1);
+            }
+        }
+    }
+    const unsigned long long bal = __ballot(viol);
+    row_viol = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;
+}
+
+// sub-pixel disparity (x16) of a winner from its two neighbours' costs; C's truncating division
+__device__ __forceinline__ int wta_subpixel(int best, int minS, int sm, int sp)
+{
+    const int denom2 = max(sm + sp - 2 * minS, 1);
+    return best * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
+}
+
+// WTA of one pixel held by a 16-lane row: S = aggregated costs (pads irrelevant), myS = this row's LDS
+// scratch (Dp int16).  Writes disp1 and the disp2 key.  All 64 lanes must call it together.
+// S = sum over directions for the Dp disparities of one pixel, spread over 16 lanes
+// (lane l16 holds d = l16*2NP .. +2NP-1).  Winner = lowest S, first d on ties (stereosgbm.cpp
+// computeDisparitySGBM: "if (Sval < minS) { minS = Sval; bestDisp = d; }").
+template <int NP, bool PAD, bool THR>
+__device__ __forceinline__ void wta_pixel(const LV<NP>& S, const SgbmGeom& g, int lane, bool live, int x1, int y,
+                                          int16_t* myS, int16_t* __restrict__ disp1, int* __restrict__ d2key)
+{
+    const int l16 = lane & 15, d0 = l16 * 2 * NP;
+    int minS, best;
+    bool row_viol;
+    wta_core<NP, PAD, THR>(S, g, lane, minS, best, row_viol);
+    lv_store<NP>(myS + d0, S);
+    __builtin_amdgcn_wave_barrier();   // LDS accesses of one wave are served in order
+    if (live && l16 == 0) {
+        const int ximg = x1 + g.minX1;
+        int out = g.invalid16;
+        if (!row_viol) {
+            int dd = best * 16;
+            if (best > 0 && best < g.D - 1) dd = wta_subpixel(best, minS, myS[best - 1], myS[best + 1]);
+            out = dd + g.minD * 16;
+            // disp2: lowest cost wins, ties go to the pixel OpenCV scans first (largest x)
+            const int x2 = ximg - best - g.minD;
+            atomicMin(&d2key[(size_t)y * g.W + x2], (minS << 16) | (0xFFFF - ximg));
+        }
+        disp1[(size_t)y * g.W + ximg] = (int16_t)out;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Second half of the fused sweep's WTA, one thread per pixel: the sweep leaves a two-word record
+// (aux0 = minS << 8 | best or -1 when the uniqueness test failed, aux1 = S[best-1] << 16 | S[best+1]);
+// this pass turns it into the sub-pixel disp1 and the disp2 candidates (atomicMin).
+__global__ void k_sgbm_fin(const int* __restrict__ aux0, const int* __restrict__ aux1, SgbmGeom g,
+                           int16_t* __restrict__ disp1, int* __restrict__ d2key)
+{
+    const int x1 = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x1 >= g.W1) return;
+    const int ximg = x1 + g.minX1;
+    const size_t o = (size_t)y * g.W + ximg;
+    const int a = aux0[o];
+    int out = g.invalid16;
+    if (a >= 0) {
+        const int minS = a >> 8, best = a & 255;
+        int dd = best * 16;
+        if (best > 0 && best < g.D - 1) {
+            const uint32_t n = (uint32_t)aux1[o];
+            dd = wta_subpixel(best, minS, (int)(n >> 16), (int)(n & 0xFFFFu));
+        }
+        out = dd + g.minD * 16;
+        atomicMin(&d2key[(size_t)y * g.W + ximg - best - g.minD], (minS << 16) | (0xFFFF - ximg));
+    }
+    disp1[o] = (int16_t)out;
+}
+
 template <int NP>
 __global__ void __launch_bounds__(256) k_sgbm_wta(const int16_t* __restrict__ Lbase, size_t vol, int nvol, SgbmGeom g,
                                                  int16_t* __restrict__ disp1, int* __restrict__ d2key)
@@ -435,50 +567,115 @@ __global__ void __launch_bounds__(256) k_sgbm_wta(const int16_t* __restrict__ Lb
 #pragma unroll
         for (int k = 0; k < NP; k++) S.r[k] = pk_add_sat(S.r[k], t.r[k]);
     }
-    uint32_t key = 0xFFFFFFFFu;
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-        const int d = d0 + 2 * k;
-        if (d < g.D) {
-            const uint32_t k0 = ((S.r[k] & 0xFFFFu) << 8) | (uint32_t)d;
-            const uint32_t k1 = ((S.r[k] >> 16) << 8) | (uint32_t)(d + 1);
-            key = min(key, min(k0, k1));
-        }
-    }
-    key = row_min_u32(key);
-    const int minS = (int)(key >> 8), best = (int)(key & 255u);
-    bool viol = false;
-    const int ur100 = 100 - g.ur;
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-        const int d = d0 + 2 * k;
-        if (d < g.D) {
-            const int s0 = (int)(S.r[k] & 0xFFFFu), s1 = (int)(S.r[k] >> 16);
-            viol |= (s0 * ur100 < minS * 100) && (abs(best - d) > 1);
-            viol |= (s1 * ur100 < minS * 100) && (abs(best - d - 1) > 1);
-        }
-    }
-    const unsigned long long bal = __ballot(viol);
-    const bool row_viol = ((bal >> ((threadIdx.x & 48))) & 0xFFFFull) != 0ull;
     int16_t* myS = s_S + (size_t)grp * g.Dp;
-    lv_store<NP>(myS + d0, S);
-    __syncthreads();
-    if (live && l16 == 0) {
-        const int ximg = x1 + g.minX1;
-        int out = g.invalid16;
-        if (!row_viol) {
-            int dd = best * 16;
-            if (best > 0 && best < g.D - 1) {
-                const int sm = myS[best - 1], sp = myS[best + 1];
-                const int denom2 = max(sm + sp - 2 * minS, 1);
-                dd = best * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
-            }
-            out = dd + g.minD * 16;
-            // disp2: lowest cost wins, ties go to the pixel OpenCV scans first (largest x)
-            const int x2 = ximg - best - g.minD;
-            atomicMin(&d2key[(size_t)y * g.W + x2], (minS << 16) | (0xFFFF - ximg));
+    const int lane = threadIdx.x & 63;
+    if (g.ur < 100) {
+        if (g.D == g.Dp) wta_pixel<NP, false, true>(S, g, lane, live, x1, y, myS, disp1, d2key);
+        else wta_pixel<NP, true, true>(S, g, lane, live, x1, y, myS, disp1, d2key);
+    } else {
+        wta_pixel<NP, true, false>(S, g, lane, live, x1, y, myS, disp1, d2key);
+    }
+}
+
+// Last aggregation direction (predecessor (x, y-1), swept top to bottom) fused with the WTA: the wave
+// walks 4 adjacent image columns; per row it reads C and the other directions' L volumes, advances
+// its own path in registers, sums and picks the winner -- this direction's L is never written and
+// the WTA needs no pass of its own.
+template <int NP, int NV, bool PAD>
+__global__ void __launch_bounds__(256) k_sgbm_vwta(const int16_t* __restrict__ C, const int16_t* __restrict__ Lbase, size_t vol,
+                                                  SgbmGeom g, int* __restrict__ aux0, int* __restrict__ aux1)
+{
+    extern __shared__ int16_t s_S[];  // [blockDim/16][2][Dp]
+    const int lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int x1 = wave * 4 + row;
+    if (wave * 4 >= g.W1) return;
+    const bool live = x1 < g.W1;
+    const int xc = live ? x1 : g.W1 - 1;          // dead rows shadow a valid column, never store
+    const int d0 = l16 * 2 * NP;
+    unsigned padreg = 0;
+    if (PAD) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
+    }
+    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
+    const size_t stride = (size_t)g.W1 * g.Dp;
+    const uint32_t start = (uint32_t)(xc * g.Dp + d0);   // lane offset inside one image row of the volume
+    int16_t* myS = s_S + (size_t)(threadIdx.x >> 4) * 2 * g.Dp;   // two rows of S: this step's and the previous one's
+    LV<NP> Lp;
+#pragma unroll
+    for (int k = 0; k < NP; k++) Lp.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;
+    uint32_t delta2 = P2_2;
+    // The winner's record is written one step late: its two neighbour costs come back from LDS while
+    // the next row is being computed, so the sweep never waits on the LDS round trip.
+    const bool writer = live && l16 == 0;
+    uint32_t aoff = (uint32_t)(x1 + g.minX1);   // record index of the PREVIOUS row's pixel
+    int prec = -1, pbest = 0, par = 0;
+    constexpr int PF = 3;
+    LV<NP> cbuf[PF], lbuf[PF][NV];
+    // wave-uniform row pointers advance by one row per step; the lane part stays a 32-bit offset
+    const int16_t* rowC = C;
+    const int16_t* rowL = Lbase;
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        if (k < g.H) {
+            cbuf[k] = lv_load<NP>(rowC + start);
+#pragma unroll
+            for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load<NP>(rowL + (size_t)v * vol + start);
+            rowC += stride;
+            rowL += stride;
         }
-        disp1[(size_t)y * g.W + ximg] = (int16_t)out;
+    }
+    for (int y0 = 0; y0 < g.H; y0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int y = y0 + k;
+            if (y < g.H) {
+                const LV<NP> Cv = cbuf[k];
+                LV<NP> S = lbuf[k][0];
+#pragma unroll
+                for (int v = 1; v < NV; v++)
+#pragma unroll
+                    for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], lbuf[k][v].r[q]);
+                if (y + PF < g.H) {
+                    cbuf[k] = lv_load<NP>(rowC + start);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load<NP>(rowL + (size_t)v * vol + start);
+                    rowC += stride;
+                    rowL += stride;
+                }
+                const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
+                const int16_t* prevS = myS + (par ^ 1) * g.Dp;
+                const uint32_t nb = ((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1];
+                const LV<NP> L = path_step<NP>(Cv, Lp, delta2, P1_2, padreg);
+                const uint32_t mn = row_min_u32(lane_min16<NP>(L));
+                delta2 = pk_add(pk_rep((int)mn), P2_2);
+                Lp = L;
+#pragma unroll
+                for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], L.r[q]);
+                int minS, best;
+                bool row_viol;
+                wta_core<NP, PAD, true>(S, g, lane, minS, best, row_viol);
+                lv_store<NP>(myS + par * g.Dp + d0, S);
+                if (writer && y > 0) {
+                    aux0[aoff] = prec;
+                    aux1[aoff] = (int)nb;
+                }
+                if (y > 0) aoff += (uint32_t)g.W;
+                prec = row_viol ? -1 : ((minS << 8) | best);
+                pbest = best;
+                par ^= 1;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // the last row's record
+        const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
+        const int16_t* prevS = myS + (par ^ 1) * g.Dp;
+        if (writer) {
+            aux0[aoff] = prec;
+            aux1[aoff] = (int)(((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1]);
+        }
     }
 }
 
@@ -659,7 +856,7 @@ static PathPlan make_plan(const SgbmGeom& g, int mode)
     // steps = negated predecessor offsets.  MODE_SGBM predecessors: (x-1,y) (x+1,y) (x-1,y-1) (x,y-1)
     // (x+1,y-1); MODE_HH adds (x-1,y+1) (x,y+1) (x+1,y+1).  Longest lines first.
     static const int sx5[] = { 1, -1, 1, -1, 0 }, sy5[] = { 0, 0, 1, 1, 1 };
-    static const int sx8[] = { 1, -1, 1, -1, 1, -1, 0, 0 }, sy8[] = { 0, 0, 1, 1, -1, -1, 1, -1 };
+    static const int sx8[] = { 1, -1, 1, -1, 1, -1, 0, 0 }, sy8[] = { 0, 0, 1, 1, -1, -1, -1, 1 };   // (0,+1) last: fused with the WTA
     PathPlan p;
     p.n_dirs = mode == 1 ? 8 : 5;
     p.first_wave[0] = 0;
@@ -674,8 +871,15 @@ static PathPlan make_plan(const SgbmGeom& g, int mode)
 }
 
 template <int NP>
-static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size_t vol, int16_t* d_disp_raw)
+static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, size_t vol, int16_t* d_disp_raw)
 {
+    // the last direction of the plan is the top-down vertical one: it runs fused with the WTA
+    PathPlan plan = plan_all;
+    const bool fuse = ctx->tune_fuse_wta != 0 && g.ur < 100;   // the fused sweep only carries the threshold form of the uniqueness test
+    if (fuse) {
+        plan.n_dirs = plan_all.n_dirs - 1;
+        for (int k = plan.n_dirs; k < VO_MAX_DIRS; k++) plan.first_wave[k + 1] = plan.first_wave[plan.n_dirs];
+    }
     {
         StageTimer t(ctx, VO_T_SGBM_AGG);
         const int nwaves = plan.first_wave[plan.n_dirs];
@@ -690,10 +894,22 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
     {
         StageTimer t(ctx, VO_T_SGBM_WTA);
         VO_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->ccl_size, D2_EMPTY, (size_t)g.W * g.H, ctx->stream));
-        const long long npix = (long long)g.W1 * g.H;
-        const size_t sh = (size_t)16 * g.Dp * sizeof(int16_t);
-        hipLaunchKernelGGL((k_sgbm_wta<NP>), dim3((unsigned)((npix + 15) / 16)), dim3(256), sh, ctx->stream, ctx->S, vol, plan.n_dirs,
-                           g, ctx->disp_tmp, ctx->ccl_size);
+        const size_t sh = (size_t)16 * g.Dp * sizeof(int16_t);   // one row of S per 16-lane group (the fused sweep keeps two)
+        if (fuse) {
+            const int nw = div_up(g.W1, 4);
+            // the sweep leaves a two-word record per pixel in ccl_label / ccl_runlen (free until the speckle
+            // filter); k_sgbm_fin turns the records into disp1 + the disp2 atomicMin for all pixels in parallel
+            // (an atomic or an LDS round trip inside the sequential sweep costs it a third of its time)
+#define LAUNCH_VWTA(NV, PAD) hipLaunchKernelGGL((k_sgbm_vwta<NP, NV, PAD>), dim3(div_up(nw, 4)), dim3(256), 2 * sh, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen)
+            if (plan.n_dirs == 4) { if (g.D == g.Dp) LAUNCH_VWTA(4, false); else LAUNCH_VWTA(4, true); }
+            else { if (g.D == g.Dp) LAUNCH_VWTA(7, false); else LAUNCH_VWTA(7, true); }
+#undef LAUNCH_VWTA
+            hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
+        } else {
+            const long long npix = (long long)g.W1 * g.H;
+            hipLaunchKernelGGL((k_sgbm_wta<NP>), dim3((unsigned)((npix + 15) / 16)), dim3(256), sh, ctx->stream, ctx->S, vol, plan.n_dirs,
+                               g, ctx->disp_tmp, ctx->ccl_size);
+        }
         hipLaunchKernelGGL(k_sgbm_lr, dim3(div_up(g.W, 256), g.H), dim3(256), 0, ctx->stream, ctx->disp_tmp, ctx->ccl_size, g, d_disp_raw);
         VO_CHECK_LAUNCH(ctx);
     }
@@ -747,7 +963,7 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
         ctx->S_vols = plan.n_dirs;
     }
     ctx->last_cells = (int64_t)g.W1 * h * g.D;
-    ctx->last_paths = plan.n_dirs;
+    ctx->last_paths = (ctx->tune_fuse_wta && g.ur < 100) ? plan.n_dirs - 1 : plan.n_dirs;   // directions inside the k_sgbm_paths launch
     {
         StageTimer t(ctx, VO_T_SGBM_COST);
         hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,

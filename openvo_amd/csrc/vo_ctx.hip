@@ -114,7 +114,6 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s)", prop.name, prop.gcnArchName);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
-    if ((e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
     (void)hipEventCreateWithFlags(&ctx->sgbm_done, hipEventDisableTiming);
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
@@ -131,7 +130,6 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     }
     ctx->stage_bytes = npx * 3;
     DALLOC(ctx->stage_in, ctx->stage_bytes * 2);
-    DALLOC(ctx->stage_in2, ctx->stage_bytes * 2);
     for (int c = 0; c < 2; c++) { DALLOC(ctx->map1[c], npx * 2); DALLOC(ctx->map2[c], npx); }
     DALLOC(ctx->planesL, npx * 2); DALLOC(ctx->planesR, npx * 6);
     ctx->vol_cells = npx * (size_t)((max_disp + 31) & ~31);
@@ -169,6 +167,8 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
         g_create_err = "hipHostMalloc failed"; vo_destroy(ctx); return VO_E_HIP;
     }
     if (const char* e3 = getenv("VO_PATH_PF")) { int v = atoi(e3); if (v == 2 || v == 4 || v == 8) ctx->tune_path_pf = v; }
+    if (const char* e8 = getenv("VO_ENGINES")) { int v = atoi(e8); if (v >= 1 && v <= vo_ctx::MAX_ENGINES) ctx->n_engines = v; }
+    if (const char* e7 = getenv("VO_FUSE_WTA")) ctx->tune_fuse_wta = atoi(e7) ? 1 : 0;
     if (const char* e5 = getenv("VO_SWEEP_XT")) { int v = atoi(e5); if (v == 8 || v == 16) ctx->tune_sweep_xt = v; }
     if (const char* e6 = getenv("VO_SWEEP_TY")) { int v = atoi(e6); if (v >= 4 && v <= 4096) ctx->tune_sweep_ty = v; }
     *out = ctx;
@@ -179,8 +179,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) if (ctx->la_stream[k]) (void)hipStreamSynchronize(ctx->la_stream[k]);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int s = 0; s <= VO_NUM_SLOTS; s++) {
         FrameSlot& f = ctx->slots[s];
@@ -188,7 +187,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         for (void* p : ps) if (p) (void)hipFree(p);
         if (f.ready) (void)hipEventDestroy(f.ready);
     }
-    void* ps[] = { ctx->stage_in, ctx->stage_in2, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
+    void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
                    ctx->C, ctx->S, ctx->disp_raw, ctx->disp_tmp, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->pyr_img, ctx->pyr_blur,
                    ctx->pyr_mask, ctx->pyr_score, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->cand_pos,
                    ctx->cand_resp, ctx->candA_pos, ctx->candA_resp, ctx->candB_pos, ctx->candB_resp, ctx->kp_pos, ctx->pyr_tmp16, ctx->counters, ctx->host_mask_dev, ctx->mq, ctx->mt,
@@ -199,17 +198,16 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->staged) (void)hipFree(ctx->staged);
     if (ctx->sgbm_done) (void)hipEventDestroy(ctx->sgbm_done);
-    {
-        vo_ctx::SgbmWs& a = ctx->ws_alt;
-        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.disp_raw, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->stage_in3 };
+    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) {
+        vo_ctx::SgbmWs& a = ctx->ws_alt[k];
+        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.disp_raw, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->la_stage[k] };
         for (void* q : pa) if (q) (void)hipFree(q);
         if (a.done) (void)hipEventDestroy(a.done);
-        if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+        if (ctx->la_stream[k]) (void)hipStreamDestroy(ctx->la_stream[k]);
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 
@@ -223,8 +221,8 @@ extern "C" int vo_device_name(const vo_ctx* ctx, char* buf, int buflen)
 extern "C" int vo_synchronize(vo_ctx* ctx)
 {
     if (!ctx) return VO_E_ARG;
-    if (ctx->stream3) VO_HIP(ctx, hipStreamSynchronize(ctx->stream3));
-    if (ctx->stream2) VO_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++)
+        if (ctx->la_stream[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream[k]));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }
@@ -412,18 +410,14 @@ extern "C" int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preproc
     return VO_OK;
 }
 
-// swap the main stream / staging (and for engine 1 the SGBM workspace) with a look-ahead engine's;
+// swap the main stream / staging (and for engines >= 1 the SGBM workspace) with a look-ahead engine's;
 // calling it twice restores the context
 static void engine_swap(vo_ctx* ctx, int engine)
 {
-    if (engine == 0) {
-        std::swap(ctx->stream, ctx->stream2);
-        std::swap(ctx->stage_in, ctx->stage_in2);
-        return;
-    }
-    std::swap(ctx->stream, ctx->stream3);
-    std::swap(ctx->stage_in, ctx->stage_in3);
-    vo_ctx::SgbmWs& a = ctx->ws_alt;
+    std::swap(ctx->stream, ctx->la_stream[engine]);
+    std::swap(ctx->stage_in, ctx->la_stage[engine]);
+    if (engine == 0) return;
+    vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
     std::swap(ctx->planesL, a.planesL); std::swap(ctx->planesR, a.planesR);
     std::swap(ctx->C, a.C); std::swap(ctx->S, a.S); std::swap(ctx->S_vols, a.S_vols);
     std::swap(ctx->disp_raw, a.disp_raw); std::swap(ctx->disp_tmp, a.disp_tmp);
@@ -431,9 +425,14 @@ static void engine_swap(vo_ctx* ctx, int engine)
     std::swap(ctx->sgbm_done, a.done); std::swap(ctx->sgbm_done_valid, a.done_valid);
 }
 
-static int alloc_alt_workspace(vo_ctx* ctx)
+static int engine_prepare(vo_ctx* ctx, int engine)
 {
-    vo_ctx::SgbmWs& a = ctx->ws_alt;
+    if (!ctx->la_stream[engine]) {
+        VO_HIP(ctx, hipStreamCreateWithFlags(&ctx->la_stream[engine], hipStreamNonBlocking));
+        VO_HIP(ctx, hipMalloc((void**)&ctx->la_stage[engine], ctx->stage_bytes * 2 + 256));
+    }
+    if (engine == 0 || ctx->ws_alt[engine].ready) return VO_OK;
+    vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
     const size_t npx = (size_t)ctx->max_w * ctx->max_h;
     const int vols = ctx->S_vols > 5 ? ctx->S_vols : 5;
     VO_HIP(ctx, hipMalloc((void**)&a.planesL, npx * 2 * 4 + 256));
@@ -447,9 +446,7 @@ static int alloc_alt_workspace(vo_ctx* ctx)
     VO_HIP(ctx, hipMalloc((void**)&a.ccl_label, npx * 4 + 256));
     VO_HIP(ctx, hipMalloc((void**)&a.ccl_size, npx * 4 + 256));
     VO_HIP(ctx, hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
-    VO_HIP(ctx, hipMalloc((void**)&ctx->stage_in3, ctx->stage_bytes * 2 + 256));
-    VO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
-    ctx->ws_alt_ready = true;
+    a.ready = true;
     return VO_OK;
 }
 
@@ -476,10 +473,8 @@ extern "C" int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int pre
     const size_t per = (size_t)w * h * ctx->staged_ch;
     // alternate between the two look-ahead engines
     const int engine = ctx->next_engine;
-    if (engine == 1 && !ctx->ws_alt_ready) {
-        if ((rc = alloc_alt_workspace(ctx))) return rc;
-    }
-    ctx->next_engine ^= 1;
+    if ((rc = engine_prepare(ctx, engine))) return rc;
+    ctx->next_engine = (engine + 1) % ctx->n_engines;
     engine_swap(ctx, engine);
     {
         StageTimer t(ctx, VO_T_UPLOAD);

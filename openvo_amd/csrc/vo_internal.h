@@ -47,12 +47,14 @@ struct FrameSlot {
 struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // look-ahead stream (vo_prefetch_*): next pair's SGBM overlaps this pair's ORB / pose
-    uint8_t* stage_in2 = nullptr;    // staging of the look-ahead stream
-    // second look-ahead engine: its own stream, staging and SGBM workspace, so that two pairs' SGBM
-    // can be in flight (one pair's latency-bound kernels overlap the other's bandwidth-bound ones)
-    hipStream_t stream3 = nullptr;
-    uint8_t* stage_in3 = nullptr;
+    // look-ahead engines (vo_prefetch_*): each has its own stream and staging; engine 0 shares the main
+    // SGBM workspace, engines 1.. own an alternate one, so several pairs' SGBM can be in flight (one
+    // pair's latency-bound kernels overlap another's bandwidth-bound ones)
+    static const int MAX_ENGINES = 4;
+    hipStream_t la_stream[MAX_ENGINES] = {};
+    uint8_t* la_stage[MAX_ENGINES] = {};
+    hipEvent_t sgbm_done = nullptr;  // end of the latest SGBM run in the CURRENT workspace (any stream)
+    bool sgbm_done_valid = false;
     struct SgbmWs {
         uint32_t *planesL = nullptr, *planesR = nullptr;
         int16_t *C = nullptr, *S = nullptr, *disp_raw = nullptr, *disp_tmp = nullptr;
@@ -60,11 +62,10 @@ struct vo_ctx {
         int S_vols = 0;
         hipEvent_t done = nullptr;
         bool done_valid = false;
-    } ws_alt;
-    bool ws_alt_ready = false;
+        bool ready = false;
+    } ws_alt[MAX_ENGINES];           // [0] unused (engine 0 uses the main workspace)
+    int n_engines = 3;               // VO_ENGINES
     int next_engine = 0;
-    hipEvent_t sgbm_done = nullptr;  // end of the latest SGBM run on either stream (shared workspaces)
-    bool sgbm_done_valid = false;
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;
     std::string err;
     char devname[256] = {0};
@@ -160,6 +161,7 @@ struct vo_ctx {
 
     // tuning knobs (environment: VO_PATH_PF, VO_SWEEP_XT, VO_SWEEP_TY), read once in vo_create
     int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 15;
+    int tune_fuse_wta = 1;          // VO_FUSE_WTA: last (top-down vertical) path fused with the WTA
 
     // timing
     bool timing = false;

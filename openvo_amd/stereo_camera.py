@@ -5,6 +5,7 @@ Same constructor, classmethod, attributes and methods; the per-pair work of comp
 MI355X and its three return values are lazy device-backed array-likes (DeviceImage) that
 download on first numpy use, so StereoOdometer can keep the whole frame on the GPU.
 """
+import os
 import pickle
 
 import numpy as np
@@ -63,7 +64,8 @@ class StereoCamera:
         self.stereoSGBM = StereoSGBM(self._ctx, sgbm_params)
         self._slot_owner = [None] * _native.VO_NUM_SLOTS   # weak bookkeeping: FrameHandle per slot
         self._next_slot = 0
-        self.lookahead = 2           # staged pairs: how many following pairs run their SGBM ahead (0, 1 or 2)
+        # staged pairs: how many following pairs run their SGBM ahead (0..4; env VO_LOOKAHEAD overrides)
+        self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "3"))
         self._lookahead = []         # [((index, preprocessed), slot, (w, h))] of the pairs in flight
         self._n_staged = 0
 

@@ -48,6 +48,28 @@ def test_sgbm_parameter_corners(oracle, ctx_small, params):
     assert np.array_equal(got, ref)
 
 
+@pytest.fixture(scope="module")
+def ctx_wide():
+    from openvo_amd import _native
+    c = _native.Context(0, 640, 256, 256, 1000)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("ndisp,ur,mode", [(160, 10, 0), (192, 15, 1), (256, 10, 0), (240, 5, 1), (96, 99, 0), (64, 100, 0), (128, 0, 1)])
+def test_sgbm_wide_disparity_ranges(oracle, ctx_wide, ndisp, ur, mode):
+    """Every register-count variant of the aggregation/WTA kernels (D/32 = 2..8, padded and exact),
+    both path sets, and both forms of the uniqueness test (threshold form < 100 <= product form)."""
+    c, L, R = _pair("C1", 2)
+    L, R = L[:200], R[:200]
+    p = dict(minDisparity=0, numDisparities=ndisp, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, preFilterCap=63,
+             uniquenessRatio=ur, speckleWindowSize=0, speckleRange=0)
+    ctx_wide.set_sgbm(p, mode)
+    got = ctx_wide.sgbm_compute_host(L, R)
+    ref = oracle.sgbm_compute(L, R, p, mode)
+    assert np.array_equal(got, ref), "%d pixels differ" % int((got != ref).sum())
+
+
 def test_sgbm_random_noise_images(oracle, ctx_small):
     rng = np.random.default_rng(5)
     L = rng.integers(0, 256, (96, 160), dtype=np.uint8)
