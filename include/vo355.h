@@ -73,6 +73,11 @@ int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
  * asynchronously; later calls that use the slot wait for it on the device.  Lets the next pair's
  * disparity overlap the current pair's ORB / matching / pose kernels. */
 int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
+/* look-ahead keypoints: when enabled, every vo_prefetch_staged_pair also runs the ORB extraction
+ * (same arguments as vo_orb_detect_and_compute) behind the SGBM on the engine's stream; a later
+ * vo_orb_detect_and_compute on that slot with the SAME arguments only waits and downloads, any
+ * other arguments recompute.  Results are identical either way. */
+int vo_set_lookahead_orb(vo_ctx* ctx, int enable, int nfeatures, int mask_mode, int min_disp16, int max_disp16);
 /* self.stereoSGBM.compute(L, R) [:51]: int16 disparity x16 of the slot's pair; kept on the
  * device; disp16_out (h*w) may be NULL */
 int vo_sgbm_compute(vo_ctx* ctx, int slot, int16_t* disp16_out);

@@ -21,6 +21,7 @@ SYMBOLS = [
     "vo_create", "vo_destroy", "vo_last_error", "vo_device_name", "vo_synchronize",
     "vo_set_rectify_maps", "vo_set_sgbm", "vo_set_Q", "vo_set_roi", "vo_upload_pair",
     "vo_stage_pairs_alloc", "vo_stage_pair", "vo_load_staged_pair", "vo_prefetch_staged_pair",
+    "vo_set_lookahead_orb",
     "vo_sgbm_compute", "vo_sgbm_compute_host", "vo_download_disparity_f32", "vo_download_xyz",
     "vo_download_left", "vo_download_right", "vo_cvt_bgr2gray", "vo_remap", "vo_reproject_to_3d",
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints",
@@ -78,6 +79,7 @@ def lib():
         L.vo_stage_pair.argtypes = [vp, ci, vp, vp]
         L.vo_load_staged_pair.argtypes = [vp, ci, ci, ci]
         L.vo_prefetch_staged_pair.argtypes = [vp, ci, ci, ci]
+        L.vo_set_lookahead_orb.argtypes = [vp, ci, ci, ci, ci, ci]
         L.vo_sgbm_compute.argtypes = [vp, ci, vp]
         L.vo_sgbm_compute_host.argtypes = [vp, vp, vp, ci, ci, vp]
         for f in (L.vo_download_disparity_f32, L.vo_download_xyz, L.vo_download_left, L.vo_download_right):
@@ -123,6 +125,7 @@ class Context:
         if rc != 0:
             raise VoError(rc, (self._lib.vo_last_error(None) or b"").decode())
         self._h = h
+        self._la_orb = None
         self.device, self.max_w, self.max_h, self.max_disp, self.max_kp = device, max_w, max_h, max_disp, max_kp
         self.kp_cap = max_kp * 2 + 1024
 
@@ -254,6 +257,13 @@ class Context:
     @staticmethod
     def _trim(b, n):
         return {k: v[:n] for k, v in b.items()}
+
+    def lookahead_orb(self, nfeatures, mask_mode, min_d16, max_d16):
+        """Ask the look-ahead engines to extract keypoints with these parameters behind each prefetched SGBM."""
+        key = (int(nfeatures), int(mask_mode), int(min_d16), int(max_d16))
+        if key != self._la_orb:
+            self._ck(self._lib.vo_set_lookahead_orb(self._h, 1, *key))
+            self._la_orb = key
 
     def orb_slot(self, slot, nfeatures, mask_mode, min_d16=0, max_d16=0):
         cap = self.kp_cap

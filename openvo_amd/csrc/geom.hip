@@ -299,10 +299,10 @@ extern "C" int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio
         rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->m_idx, ctx->m_dist);
         if (rc) return rc;
         hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(64), 0, ctx->stream, ctx->m_idx, ctx->m_dist, a.n_kp, ratio, a.kp_xy,
-                           b.kp_xy, ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, ctx->counters);
+                           b.kp_xy, ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, ctx->m_count);
         VO_CHECK_LAUNCH(ctx);
         // 3-D lookups for every query slot position (n_kp upper bound); only the first M are meaningful
-        VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->counters, 4, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->m_count, 4, hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     const int m = *(int32_t*)ctx->pinned;
@@ -1099,7 +1099,7 @@ extern "C" int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, i
     float* d_qb = (float*)wsp; wsp += (size_t)nq * 12;
     float* d_ra = (float*)wsp; wsp += (size_t)nq * 12;
     float* d_rb = (float*)wsp;
-    int* d_m = ctx->counters;  // k_ratio_compact writes M here
+    int* d_m = ctx->m_count;  // k_ratio_compact writes M here
     int rc;
     {
         StageTimer t(ctx, VO_T_MATCH);

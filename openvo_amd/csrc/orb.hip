@@ -589,12 +589,15 @@ __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev* __restric
 // ---------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------
-int orb_run(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img_stride, int w, int h, int nfeatures, int mask_mode,
-            const int16_t* d_disp16, int disp_stride, int min_d16, int max_d16, const uint8_t* d_mask, int mask_stride)
+// Enqueue one extraction on ctx->stream (scratch: ctx->orb).  The keypoint count lands in the slot's
+// pinned word; orb_finish() reads it once the stream (or the slot's `ready` event) has been waited for.
+static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img_stride, int w, int h, int nfeatures, int mask_mode,
+                       const int16_t* d_disp16, int disp_stride, int min_d16, int max_d16, const uint8_t* d_mask, int mask_stride)
 {
+    fs->has_kp = false;
     if (w < 2 * EDGE + 8 || h < 2 * EDGE + 8) {
         // every level is cleared by runByImageBorder
-        fs->n_kp = 0; fs->has_kp = true;
+        *fs->n_kp_host = 0;
         return VO_OK;
     }
     int rc = orb_prepare_tables(ctx, w, h);
@@ -620,38 +623,63 @@ int orb_run(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img_stride, in
     const LevelsDev* dL = (const LevelsDev*)ctx->d_levels;
     const int with_mask = mask_mode != 0;
     StageTimer t(ctx, VO_T_ORB);
-    VO_HIP(ctx, hipMemsetAsync(ctx->counters, 0, (CNT_HIST + NL * 256) * sizeof(int32_t), ctx->stream));
+    VO_HIP(ctx, hipMemsetAsync(ctx->orb.counters, 0, (CNT_HIST + NL * 256) * sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(k_orb_level0, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_img, img_stride, w, h, mask_mode,
-                       d_disp16, disp_stride, min_d16, max_d16, d_mask, mask_stride, ctx->pyr_img, ctx->pyr_mask);
+                       d_disp16, disp_stride, min_d16, max_d16, d_mask, mask_stride, ctx->orb.pyr_img, ctx->orb.pyr_mask);
     for (int l = 1; l < NL; l++)
         hipLaunchKernelGGL(k_orb_resize, dim3(div_up(Lh->l[l].w, 256), Lh->l[l].h), dim3(256), 0, ctx->stream, dL, l, ctx->rs_ofs,
-                           ctx->rs_coef, ctx->pyr_img, ctx->pyr_mask, with_mask);
-    hipLaunchKernelGGL(k_orb_fast, dim3(div_up(w, 64), h, NL), dim3(64), 0, ctx->stream, dL, ctx->pyr_img, ctx->pyr_score);
-    hipLaunchKernelGGL(k_orb_nms, dim3(div_up(w - 2 * EDGE, 64), div_up(h - 2 * EDGE, 16), NL), dim3(256), 0, ctx->stream, dL, ctx->pyr_score,
-                       ctx->pyr_mask, with_mask, ctx->cand_pos, ctx->cand_resp, ctx->counters);
-    hipLaunchKernelGGL(k_orb_fast_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->cand_pos, ctx->cand_resp, ctx->candA_pos, ctx->counters);
+                           ctx->rs_coef, ctx->orb.pyr_img, ctx->orb.pyr_mask, with_mask);
+    hipLaunchKernelGGL(k_orb_fast, dim3(div_up(w, 64), h, NL), dim3(64), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.pyr_score);
+    hipLaunchKernelGGL(k_orb_nms, dim3(div_up(w - 2 * EDGE, 64), div_up(h - 2 * EDGE, 16), NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_score,
+                       ctx->orb.pyr_mask, with_mask, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.counters);
+    hipLaunchKernelGGL(k_orb_fast_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.candA_pos, ctx->orb.counters);
     // upper bound of the Harris work list: every candidate of level 0
     const int maxA = ((w + 1) / 2) * ((h + 1) / 2);
-    hipLaunchKernelGGL(k_orb_harris, dim3(div_up(maxA, 256), NL), dim3(256), 0, ctx->stream, dL, ctx->pyr_img, ctx->candA_pos,
-                       ctx->candA_resp, ctx->counters);
+    hipLaunchKernelGGL(k_orb_harris, dim3(div_up(maxA, 256), NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.candA_pos,
+                       ctx->orb.candA_resp, ctx->orb.counters);
     // after the select, cand_* hold the per-level final lists; candB_* are scratch
-    hipLaunchKernelGGL(k_orb_harris_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->candA_pos, ctx->candA_resp, ctx->cand_pos,
-                       ctx->cand_resp, ctx->candB_pos, ctx->candB_resp, ctx->counters);
-    hipLaunchKernelGGL(k_orb_pack, dim3(div_up(ctx->kp_cap, 256), NL), dim3(256), 0, ctx->stream, dL, ctx->cand_pos, ctx->cand_resp,
-                       ctx->counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, ctx->kp_pos);
-    hipLaunchKernelGGL(k_orb_blur_h, dim3(div_up(w, 256), h, NL), dim3(256), 0, ctx->stream, dL, ctx->pyr_img, ctx->pyr_tmp16);
-    hipLaunchKernelGGL(k_orb_blur_v, dim3(div_up(w, 256), h, NL), dim3(256), 0, ctx->stream, dL, ctx->pyr_tmp16, ctx->pyr_blur);
-    hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->pyr_img, ctx->pyr_blur,
-                       ctx->counters, ctx->kp_cap, fs->kp_xy, fs->kp_oct, ctx->kp_pos, fs->kp_angle, fs->desc);
+    hipLaunchKernelGGL(k_orb_harris_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orb.candA_pos, ctx->orb.candA_resp, ctx->orb.cand_pos,
+                       ctx->orb.cand_resp, ctx->orb.candB_pos, ctx->orb.candB_resp, ctx->orb.counters);
+    hipLaunchKernelGGL(k_orb_pack, dim3(div_up(ctx->kp_cap, 256), NL), dim3(256), 0, ctx->stream, dL, ctx->orb.cand_pos, ctx->orb.cand_resp,
+                       ctx->orb.counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, ctx->orb.kp_pos);
+    hipLaunchKernelGGL(k_orb_blur_h, dim3(div_up(w, 256), h, NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.pyr_tmp16);
+    hipLaunchKernelGGL(k_orb_blur_v, dim3(div_up(w, 256), h, NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_tmp16, ctx->orb.pyr_blur);
+    hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.pyr_blur,
+                       ctx->orb.counters, ctx->kp_cap, fs->kp_xy, fs->kp_oct, ctx->orb.kp_pos, fs->kp_angle, fs->desc);
     VO_CHECK_LAUNCH(ctx);
-    VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->counters + CNT_TOTAL, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int total = *(int32_t*)ctx->pinned;
+    VO_HIP(ctx, hipMemcpyAsync(fs->n_kp_host, ctx->orb.counters + CNT_TOTAL, 4, hipMemcpyDeviceToHost, ctx->stream));
+    return VO_OK;
+}
+
+static int orb_finish(vo_ctx* ctx, FrameSlot* fs)
+{
+    const int total = *fs->n_kp_host;
     if (total > ctx->kp_cap)
         return vo_fail(ctx, VO_E_CAP, "%d keypoints (response ties included) exceed capacity %d; raise max_kp", total, ctx->kp_cap);
     fs->n_kp = total;
     fs->has_kp = true;
     return VO_OK;
+}
+
+int orb_run(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img_stride, int w, int h, int nfeatures, int mask_mode,
+            const int16_t* d_disp16, int disp_stride, int min_d16, int max_d16, const uint8_t* d_mask, int mask_stride)
+{
+    int rc = orb_enqueue(ctx, fs, d_img, img_stride, w, h, nfeatures, mask_mode, d_disp16, disp_stride, min_d16, max_d16, d_mask, mask_stride);
+    if (rc) return rc;
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return orb_finish(ctx, fs);
+}
+
+// extraction on a slot's left image inside the valid ROI with the fused disparity mask (mask_mode 1) or
+// none (0); enqueue only
+int orb_slot_enqueue(vo_ctx* ctx, FrameSlot& f, int nfeatures, int mask_mode, int min_disp16, int max_disp16)
+{
+    int x0 = 0, y0 = 0, x1 = f.w, y1 = f.h;
+    if (ctx->has_roi) { x0 = ctx->roi[0]; y0 = ctx->roi[1]; x1 = ctx->roi[2] < f.w ? ctx->roi[2] : f.w; y1 = ctx->roi[3] < f.h ? ctx->roi[3] : f.h; }
+    const int cw = x1 - x0, ch = y1 - y0;
+    if (cw <= 0 || ch <= 0) { f.has_kp = false; *f.n_kp_host = 0; return VO_OK; }
+    return orb_enqueue(ctx, &f, f.left + (size_t)y0 * f.w + x0, f.w, cw, ch, nfeatures, mask_mode,
+                       f.disp16 + (size_t)y0 * f.w + x0, f.w, min_disp16, max_disp16, nullptr, 0);
 }
 
 static int download_kps(vo_ctx* ctx, FrameSlot& f, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
@@ -685,14 +713,20 @@ extern "C" int vo_orb_detect_and_compute(vo_ctx* ctx, int slot, int nfeatures, i
     if (!f.has_pair) return vo_fail(ctx, VO_E_STATE, "slot %d holds no image", slot);
     if (mask_mode == 1 && !f.has_disp) return vo_fail(ctx, VO_E_STATE, "slot %d holds no disparity for the fused mask", slot);
     VO_HIP(ctx, hipSetDevice(ctx->device));
-    { int rcw = slot_wait(ctx, f); if (rcw) return rcw; }
-    int x0 = 0, y0 = 0, x1 = f.w, y1 = f.h;
-    if (ctx->has_roi) { x0 = ctx->roi[0]; y0 = ctx->roi[1]; x1 = ctx->roi[2] < f.w ? ctx->roi[2] : f.w; y1 = ctx->roi[3] < f.h ? ctx->roi[3] : f.h; }
-    const int cw = x1 - x0, ch = y1 - y0;
-    if (cw <= 0 || ch <= 0) { f.n_kp = 0; f.has_kp = true; if (n_out) *n_out = 0; return VO_OK; }
-    int rc = orb_run(ctx, &f, f.left + (size_t)y0 * f.w + x0, f.w, cw, ch, nfeatures, mask_mode,
-                     f.disp16 + (size_t)y0 * f.w + x0, f.w, min_disp16, max_disp16, nullptr, 0);
-    if (rc) return rc;
+    const int params[4] = { nfeatures, mask_mode, min_disp16, max_disp16 };
+    const bool prefetched = f.kp_pending && !memcmp(params, f.kp_params, sizeof(params));
+    f.kp_pending = false;
+    int rc;
+    if (prefetched) {
+        // the look-ahead engine extracted these keypoints behind the SGBM: wait for it, nothing to launch
+        VO_HIP(ctx, hipEventSynchronize(f.ready));
+        f.pending = false;
+    } else {
+        if ((rc = slot_wait(ctx, f))) return rc;
+        if ((rc = orb_slot_enqueue(ctx, f, nfeatures, mask_mode, min_disp16, max_disp16))) return rc;
+        VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if ((rc = orb_finish(ctx, &f))) return rc;
     return download_kps(ctx, f, kp_xy, kp_size, kp_angle, kp_response, kp_octave, desc, cap, n_out);
 }
 

@@ -611,7 +611,9 @@ __global__ void __launch_bounds__(256) k_sgbm_vwta(const int16_t* __restrict__ C
     const bool writer = live && l16 == 0;
     uint32_t aoff = (uint32_t)(x1 + g.minX1);   // record index of the PREVIOUS row's pixel
     int prec = -1, pbest = 0, par = 0;
-    constexpr int PF = 3;
+    // rows in flight: one lone wave per SIMD must cover the ~2 us HBM latency by itself, within ~128 VGPRs
+    constexpr int RPS = NP * (NV + 1);   // registers per prefetched row
+    constexpr int PF = RPS <= 20 ? 6 : RPS <= 32 ? 4 : RPS <= 48 ? 3 : 2;
     LV<NP> cbuf[PF], lbuf[PF][NV];
     // wave-uniform row pointers advance by one row per step; the lane part stays a 32-bit offset
     const int16_t* rowC = C;

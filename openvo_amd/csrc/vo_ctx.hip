@@ -91,6 +91,27 @@ extern "C" const char* vo_last_error(const vo_ctx* ctx)
     return ctx ? ctx->err.c_str() : g_create_err.c_str();
 }
 
+static int orb_ws_alloc(vo_ctx* ctx, OrbWs& o)
+{
+    const size_t cand = (size_t)ctx->cand_cap * 4 * sizeof(int32_t);   // 8 levels together: < 3.2x level 0
+    void** ps[] = { (void**)&o.pyr_img, (void**)&o.pyr_blur, (void**)&o.pyr_mask, (void**)&o.pyr_score, (void**)&o.pyr_tmp16,
+                    (void**)&o.cand_pos, (void**)&o.cand_resp, (void**)&o.candA_pos, (void**)&o.candA_resp, (void**)&o.candB_pos,
+                    (void**)&o.candB_resp, (void**)&o.kp_pos, (void**)&o.counters };
+    const size_t sz[] = { ctx->pyr_bytes, ctx->pyr_bytes, ctx->pyr_bytes, ctx->pyr_bytes, ctx->pyr_bytes * 2, cand, cand, cand, cand, cand,
+                          cand, (size_t)ctx->kp_cap * 4, 8192 * 4 };
+    for (size_t k = 0; k < sizeof(ps) / sizeof(ps[0]); k++)
+        if (hipMalloc(ps[k], sz[k] + 256) != hipSuccess) return VO_E_HIP;
+    return VO_OK;
+}
+
+static void orb_ws_free(OrbWs& o)
+{
+    void* ps[] = { o.pyr_img, o.pyr_blur, o.pyr_mask, o.pyr_score, o.pyr_tmp16, o.cand_pos, o.cand_resp, o.candA_pos, o.candA_resp,
+                   o.candB_pos, o.candB_resp, o.kp_pos, o.counters };
+    for (void* p : ps) if (p) (void)hipFree(p);
+    o = OrbWs();
+}
+
 extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int max_kp, vo_ctx** out)
 {
     if (!out) return VO_E_ARG;
@@ -140,8 +161,6 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->ccl_label, npx); DALLOC(ctx->ccl_size, npx); DALLOC(ctx->ccl_runlen, npx);
     // ORB: 8-level pyramid is < 3.2x the base image
     ctx->pyr_bytes = npx * 4;
-    DALLOC(ctx->pyr_img, ctx->pyr_bytes); DALLOC(ctx->pyr_blur, ctx->pyr_bytes);
-    DALLOC(ctx->pyr_mask, ctx->pyr_bytes); DALLOC(ctx->pyr_score, ctx->pyr_bytes);
     DALLOC(ctx->rs_ofs, (size_t)(max_w + max_h) * 2 * VO_ORB_LEVELS);
     DALLOC(ctx->rs_coef, (size_t)(max_w + max_h) * 4 * VO_ORB_LEVELS);
     DALLOC(ctx->rs_meta, 64 * VO_ORB_LEVELS);
@@ -149,11 +168,8 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     // FAST candidates after NMS are never 8-adjacent: at most ceil(w/2)*ceil(h/2) per level
     ctx->cand_cap = (int)((size_t)((max_w + 1) / 2) * ((max_h + 1) / 2));
     // (summed over the 8 levels: < 3.2x that)
-    DALLOC(ctx->cand_pos, (size_t)ctx->cand_cap * 4); DALLOC(ctx->cand_resp, (size_t)ctx->cand_cap * 4);
-    DALLOC(ctx->candA_pos, (size_t)ctx->cand_cap * 4); DALLOC(ctx->candA_resp, (size_t)ctx->cand_cap * 4);
-    DALLOC(ctx->candB_pos, (size_t)ctx->cand_cap * 4); DALLOC(ctx->candB_resp, (size_t)ctx->cand_cap * 4);
-    DALLOC(ctx->kp_pos, ctx->kp_cap); DALLOC(ctx->pyr_tmp16, ctx->pyr_bytes);
-    DALLOC(ctx->counters, 8192);
+    if (orb_ws_alloc(ctx, ctx->orb)) { g_create_err = "hipMalloc failed (ORB workspace)"; vo_destroy(ctx); return VO_E_HIP; }
+    DALLOC(ctx->m_count, 64);
     DALLOC(ctx->host_mask_dev, npx);
     DALLOC(ctx->mq, (size_t)ctx->kp_cap * 32); DALLOC(ctx->mt, (size_t)ctx->kp_cap * 32);
     DALLOC(ctx->m_idx, (size_t)ctx->kp_cap * 2); DALLOC(ctx->m_dist, (size_t)ctx->kp_cap * 2);
@@ -163,9 +179,11 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->mq_idx, ctx->kp_cap); DALLOC(ctx->mt_idx, ctx->kp_cap);
     DALLOC(ctx->red, 4096);
     ctx->pinned_bytes = 8 << 20;
-    if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->slot_words, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
         g_create_err = "hipHostMalloc failed"; vo_destroy(ctx); return VO_E_HIP;
     }
+    for (int s = 0; s <= VO_NUM_SLOTS; s++) ctx->slots[s].n_kp_host = ctx->slot_words + s;
     if (const char* e3 = getenv("VO_PATH_PF")) { int v = atoi(e3); if (v == 2 || v == 4 || v == 8) ctx->tune_path_pf = v; }
     if (const char* e8 = getenv("VO_ENGINES")) { int v = atoi(e8); if (v >= 1 && v <= vo_ctx::MAX_ENGINES) ctx->n_engines = v; }
     if (const char* e7 = getenv("VO_FUSE_WTA")) ctx->tune_fuse_wta = atoi(e7) ? 1 : 0;
@@ -188,13 +206,13 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         if (f.ready) (void)hipEventDestroy(f.ready);
     }
     void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
-                   ctx->C, ctx->S, ctx->disp_raw, ctx->disp_tmp, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->pyr_img, ctx->pyr_blur,
-                   ctx->pyr_mask, ctx->pyr_score, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->cand_pos,
-                   ctx->cand_resp, ctx->candA_pos, ctx->candA_resp, ctx->candB_pos, ctx->candB_resp, ctx->kp_pos, ctx->pyr_tmp16, ctx->counters, ctx->host_mask_dev, ctx->mq, ctx->mt,
+                   ctx->C, ctx->S, ctx->disp_raw, ctx->disp_tmp, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
                    ctx->m_idx, ctx->m_dist, ctx->pts_a, ctx->pts_b, ctx->st_a, ctx->st_b, ctx->xy_a, ctx->xy_b,
                    ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws, ctx->ransac_ws };
     for (void* p : ps) if (p) (void)hipFree(p);
+    orb_ws_free(ctx->orb);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->slot_words) (void)hipHostFree(ctx->slot_words);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->staged) (void)hipFree(ctx->staged);
     if (ctx->sgbm_done) (void)hipEventDestroy(ctx->sgbm_done);
@@ -203,6 +221,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.disp_raw, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->la_stage[k] };
         for (void* q : pa) if (q) (void)hipFree(q);
         if (a.done) (void)hipEventDestroy(a.done);
+        orb_ws_free(a.orb);
         if (ctx->la_stream[k]) (void)hipStreamDestroy(ctx->la_stream[k]);
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -362,7 +381,7 @@ extern "C" int vo_upload_pair(vo_ctx* ctx, int slot, const uint8_t* left, const 
     // the second ingest reuses the staging area: order on the stream makes that safe
     rc = ingest(ctx, 1, right, w, h, channels, preprocessed, f.right, ctx->stage_in);
     if (rc) return rc;
-    f.w = w; f.h = h; f.has_pair = true; f.has_disp = false; f.has_kp = false; f.n_kp = 0;
+    f.w = w; f.h = h; f.has_pair = true; f.has_disp = false; f.has_kp = false; f.n_kp = 0; f.kp_pending = false;
     return VO_OK;
 }
 
@@ -406,7 +425,7 @@ extern "C" int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preproc
     if (rc) return rc;
     rc = ingest(ctx, 1, ctx->staged + per * (2 * index + 1), w, h, ctx->staged_ch, preprocessed, f.right, ctx->stage_in, hipMemcpyDeviceToDevice);
     if (rc) return rc;
-    f.w = w; f.h = h; f.has_pair = true; f.has_disp = false; f.has_kp = false; f.n_kp = 0;
+    f.w = w; f.h = h; f.has_pair = true; f.has_disp = false; f.has_kp = false; f.n_kp = 0; f.kp_pending = false;
     return VO_OK;
 }
 
@@ -416,8 +435,9 @@ static void engine_swap(vo_ctx* ctx, int engine)
 {
     std::swap(ctx->stream, ctx->la_stream[engine]);
     std::swap(ctx->stage_in, ctx->la_stage[engine]);
-    if (engine == 0) return;
     vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
+    std::swap(ctx->orb, a.orb);   // every engine has its own ORB scratch
+    if (engine == 0) return;
     std::swap(ctx->planesL, a.planesL); std::swap(ctx->planesR, a.planesR);
     std::swap(ctx->C, a.C); std::swap(ctx->S, a.S); std::swap(ctx->S_vols, a.S_vols);
     std::swap(ctx->disp_raw, a.disp_raw); std::swap(ctx->disp_tmp, a.disp_tmp);
@@ -430,6 +450,7 @@ static int engine_prepare(vo_ctx* ctx, int engine)
     if (!ctx->la_stream[engine]) {
         VO_HIP(ctx, hipStreamCreateWithFlags(&ctx->la_stream[engine], hipStreamNonBlocking));
         VO_HIP(ctx, hipMalloc((void**)&ctx->la_stage[engine], ctx->stage_bytes * 2 + 256));
+        if (orb_ws_alloc(ctx, ctx->ws_alt[engine].orb)) return vo_fail(ctx, VO_E_HIP, "hipMalloc failed (look-ahead ORB workspace)");
     }
     if (engine == 0 || ctx->ws_alt[engine].ready) return VO_OK;
     vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
@@ -482,11 +503,30 @@ extern "C" int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int pre
         if (!rc) rc = ingest(ctx, 1, ctx->staged + per * (2 * index + 1), w, h, ctx->staged_ch, preprocessed, f.right, ctx->stage_in, hipMemcpyDeviceToDevice);
     }
     if (!rc) rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
+    f.w = w; f.h = h; f.has_kp = false; f.n_kp = 0; f.kp_pending = false;
+    if (!rc && ctx->la_orb) {
+        const int* q = ctx->la_orb_params;
+        rc = orb_slot_enqueue(ctx, f, q[0], q[1], q[2], q[3]);
+        if (!rc) { memcpy(f.kp_params, q, sizeof(f.kp_params)); f.kp_pending = true; }
+    }
     hipError_t e = rc ? hipSuccess : hipEventRecord(f.ready, ctx->stream);
     engine_swap(ctx, engine);
-    if (rc) return rc;
+    if (rc) { f.kp_pending = false; return rc; }
     if (e != hipSuccess) return vo_fail(ctx, VO_E_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
-    f.w = w; f.h = h; f.has_pair = true; f.has_disp = true; f.has_kp = false; f.n_kp = 0; f.pending = true;
+    f.has_pair = true; f.has_disp = true; f.pending = true;
+    return VO_OK;
+}
+
+extern "C" int vo_set_lookahead_orb(vo_ctx* ctx, int enable, int nfeatures, int mask_mode, int min_disp16, int max_disp16)
+{
+    if (!ctx) return VO_E_ARG;
+    if (enable) {
+        if (nfeatures < 0 || nfeatures > ctx->max_kp) return vo_fail(ctx, VO_E_CAP, "nfeatures %d exceeds max_kp %d", nfeatures, ctx->max_kp);
+        if (mask_mode != 0 && mask_mode != 1) return vo_fail(ctx, VO_E_ARG, "mask_mode must be 0 or 1");
+    }
+    ctx->la_orb = enable != 0;
+    ctx->la_orb_params[0] = nfeatures; ctx->la_orb_params[1] = mask_mode;
+    ctx->la_orb_params[2] = min_disp16; ctx->la_orb_params[3] = max_disp16;
     return VO_OK;
 }
 
@@ -500,7 +540,7 @@ extern "C" int vo_sgbm_compute(vo_ctx* ctx, int slot, int16_t* disp16_out)
     if ((rc = slot_wait(ctx, f))) return rc;
     rc = sgbm_run(ctx, f.left, f.right, f.w, f.h, f.disp16);
     if (rc) return rc;
-    f.has_disp = true;
+    f.has_disp = true; f.kp_pending = false;
     if (disp16_out) {
         VO_HIP(ctx, hipMemcpyAsync(disp16_out, f.disp16, (size_t)f.w * f.h * 2, hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -42,6 +42,21 @@ struct FrameSlot {
     // look-ahead: the pair was ingested + SGBM'd on the second stream; `ready` orders consumers
     hipEvent_t ready = nullptr;
     bool pending = false;
+    // look-ahead ORB: keypoints were extracted behind the SGBM on the engine's stream; the count lands
+    // in the slot's pinned word once `ready` has fired
+    int32_t* n_kp_host = nullptr;
+    bool kp_pending = false;
+    int kp_params[4] = {0, 0, 0, 0};   // nfeatures, mask_mode, min_disp16, max_disp16 of the pending run
+};
+
+// scratch of one ORB run (pyramids, candidate lists, counters); one per look-ahead engine
+struct OrbWs {
+    uint8_t *pyr_img = nullptr, *pyr_blur = nullptr, *pyr_mask = nullptr, *pyr_score = nullptr;
+    int32_t *cand_pos = nullptr, *candA_pos = nullptr, *candB_pos = nullptr, *kp_pos = nullptr, *counters = nullptr;
+    float *cand_resp = nullptr, *candA_resp = nullptr, *candB_resp = nullptr;
+    uint16_t* pyr_tmp16 = nullptr;
+    hipEvent_t done = nullptr;   // end of the latest run in this workspace (any stream)
+    bool done_valid = false;
 };
 
 struct vo_ctx {
@@ -63,7 +78,12 @@ struct vo_ctx {
         hipEvent_t done = nullptr;
         bool done_valid = false;
         bool ready = false;
+        OrbWs orb;
     } ws_alt[MAX_ENGINES];           // [0] unused (engine 0 uses the main workspace)
+    // ORB behind the look-ahead SGBM (vo_set_lookahead_orb): nfeatures, mask_mode, min/max disp16
+    bool la_orb = false;
+    int la_orb_params[4] = {0, 0, 0, 0};
+    int32_t* slot_words = nullptr;   // pinned, one word per slot (keypoint counts of pending runs)
     int n_engines = 3;               // VO_ENGINES
     int next_engine = 0;
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;
@@ -107,25 +127,13 @@ struct vo_ctx {
     OrbLevel lv[VO_ORB_LEVELS];
     int orb_w = 0, orb_h = 0;      // geometry the pyramid tables were built for
     size_t pyr_bytes = 0;
-    uint8_t* pyr_img = nullptr;    // all levels, unblurred
-    uint8_t* pyr_blur = nullptr;
-    uint8_t* pyr_mask = nullptr;
-    uint8_t* pyr_score = nullptr;  // FAST scores before NMS
+    OrbWs orb;                     // pyramids (all levels), FAST scores, candidate lists, counters
     int32_t* rs_ofs = nullptr;     // resize tables (all levels): x then y offsets
     uint16_t* rs_coef = nullptr;
     int32_t* rs_meta = nullptr;    // per level: table offsets + min/max
     void* d_levels = nullptr;      // device copy of level descriptors
-    int32_t* cand_pos = nullptr;   // [level][cand_cap]
-    float* cand_resp = nullptr;
-    int32_t* candA_pos = nullptr;  // after FAST retainBest
-    float* candA_resp = nullptr;
-    int32_t* candB_pos = nullptr;  // scratch of the Harris select
-    float* candB_resp = nullptr;
-    int32_t* kp_pos = nullptr;     // level-local pixel index of each final keypoint
-    uint16_t* pyr_tmp16 = nullptr; // row pass of the Gaussian blur
     char rs_meta_host[1024];       // host copy of the level descriptors (LevelsDev)
     int orb_quota_nfeatures = -1;  // nfeatures the device quotas were uploaded for
-    int32_t* counters = nullptr;   // misc device counters / histograms
     int cand_cap = 0;
     uint8_t* host_mask_dev = nullptr;  // explicit mask upload (scratch)
 
@@ -133,6 +141,7 @@ struct vo_ctx {
     uint8_t* mq = nullptr;
     uint8_t* mt = nullptr;
     int32_t* m_idx = nullptr;
+    int32_t* m_count = nullptr;    // match counter of the ratio filter
     int32_t* m_dist = nullptr;
     float* pts_a = nullptr;
     float* pts_b = nullptr;
@@ -207,6 +216,7 @@ int xfer_flush(vo_ctx* ctx);
 
 // make the main stream wait for a slot whose look-ahead work may still be running
 int slot_wait(vo_ctx* ctx, FrameSlot& f);
+int orb_slot_enqueue(vo_ctx* ctx, FrameSlot& f, int nfeatures, int mask_mode, int min_disp16, int max_disp16);
 
 // implemented in the per-stage files
 int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);

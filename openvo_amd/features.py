@@ -178,12 +178,15 @@ class ORB:
             # fused path: image, disparity-range mask, keypoints and descriptors never leave the GPU
             frame = image.frame
             if mask is None:
+                self._ctx.lookahead_orb(self.nfeatures, 0, 0, 0)
                 arr = self._ctx.orb_slot(frame.slot, self.nfeatures, 0)
             else:
                 # d >= lo and d <= hi on d = disp16/16 (exact in float32) <=> integer compare
                 # (the reference compares float32 arrays with Python numbers: thresholds round to float32)
                 lo16 = int(np.ceil(float(np.float32(mask.lo)) * 16.0))
                 hi16 = int(np.floor(float(np.float32(mask.hi)) * 16.0))
+                # frames prefetched from here on get their keypoints extracted right behind their SGBM
+                self._ctx.lookahead_orb(self.nfeatures, 1, lo16, hi16)
                 arr = self._ctx.orb_slot(frame.slot, self.nfeatures, 1, lo16, hi16)
         else:
             img = np.asarray(image)
