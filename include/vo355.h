@@ -34,7 +34,7 @@ enum {
     VO_E_NUMERIC = -5  /* degenerate input (Umeyama: <3 points / colinear) */
 };
 
-#define VO_NUM_SLOTS 7 /* frame slots per context: the odometer keeps prev, current, next; two more
+#define VO_NUM_SLOTS 10 /* frame slots per context: the odometer keeps prev, current, next; two more
                           may hold look-ahead pairs */
 
 /* lifetime ------------------------------------------------------------------------- */

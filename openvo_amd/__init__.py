@@ -5,6 +5,13 @@
 mirrors `from openVO import ...` (reference __init__.py:2-5).  The hot path runs in
 libvo355.so (hand-written HIP for gfx950, C ABI in include/vo355.h); there is no CPU fallback.
 """
+import os as _os
+
+# The look-ahead engines run on their own HIP streams; the runtime multiplexes streams onto 4 hardware
+# queues by default, which would serialise engines that happen to share one.  Must be set before the
+# HIP runtime initialises (a process that has already created a HIP context keeps its own setting).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .stereo_camera import StereoCamera
 from .stereo_odometer import StereoOdometer
 from .utils.rot2RPY import rot2RPY

@@ -358,7 +358,7 @@ struct PathPlan {
 
 template <int NP, int PF>
 __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ C, int16_t* __restrict__ Lbase, size_t vol,
-                                                   SgbmGeom g, PathPlan plan)
+                                                   SgbmGeom g, PathPlan plan, int16_t* __restrict__ dump)
 {
     const int lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -400,22 +400,32 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
     for (int k = 0; k < NP; k++) Lp.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;  // predecessor outside: zeros, min 0
     uint32_t delta2 = P2_2;
 
+    // No lane-dependent branch may guard a load or a store in the loop: behind one the compiler has to
+    // drain the whole memory queue (s_waitcnt vmcnt(0)) at the join and the prefetch depth is lost.
+    // So every lane always loads (index clamped to its line) and always stores (lanes past the end of
+    // their line write their 16..32 bytes into a dump area).
+    const int last = max(n, 1) - 1;
+    int16_t* const sink = dump + lane * 2 * NP;
     LV<NP> cbuf[PF];  // PF = software prefetch depth (steps)
 #pragma unroll
-    for (int k = 0; k < PF; k++) cbuf[k] = k < n ? lv_load<NP>(cp + (ptrdiff_t)k * stride) : lv_fill<NP>(0);
+    for (int k = 0; k < PF; k++) cbuf[k] = lv_load<NP>(cp + (ptrdiff_t)min(k, last) * stride);
+    const int16_t* pld = cp + (ptrdiff_t)min(PF, last) * stride;   // next cell to prefetch
+    int16_t* pst = lp;                                              // cell of the current step
+    // (the trip count is rounded up to whole groups of PF steps -- the surplus steps only feed the sink --
+    // so that the unrolled body is straight-line code and the waits stay partial)
     for (int i0 = 0; i0 < nmax; i0 += PF) {
 #pragma unroll
         for (int k = 0; k < PF; k++) {
             const int i = i0 + k;
-            if (i < nmax) {
-                const LV<NP> Cv = cbuf[k];
-                if (i + PF < n) cbuf[k] = lv_load<NP>(cp + (ptrdiff_t)(i + PF) * stride);
-                const LV<NP> L = path_step<NP>(Cv, Lp, delta2, P1_2, padreg);
-                const uint32_t mn = row_min_u32(lane_min16<NP>(L));
-                delta2 = pk_add(pk_rep((int)mn), P2_2);
-                Lp = L;
-                if (i < n) lv_store<NP>(lp + (ptrdiff_t)i * stride, L);
-            }
+            const LV<NP> Cv = cbuf[k];
+            cbuf[k] = lv_load<NP>(pld);
+            pld += (i + PF < last) ? stride : 0;
+            const LV<NP> L = path_step<NP>(Cv, Lp, delta2, P1_2, padreg);
+            const uint32_t mn = row_min_u32(lane_min16<NP>(L));
+            delta2 = pk_add(pk_rep((int)mn), P2_2);
+            Lp = L;
+            lv_store<NP>(i < n ? pst : sink, L);
+            pst += stride;
         }
     }
 }
@@ -886,11 +896,11 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
         StageTimer t(ctx, VO_T_SGBM_AGG);
         const int nwaves = plan.first_wave[plan.n_dirs];
         if (ctx->tune_path_pf == 8 && NP <= 4)
-            hipLaunchKernelGGL((k_sgbm_paths<NP, 8>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan);
+            hipLaunchKernelGGL((k_sgbm_paths<NP, 8>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump);
         else if (ctx->tune_path_pf == 2)
-            hipLaunchKernelGGL((k_sgbm_paths<NP, 2>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan);
+            hipLaunchKernelGGL((k_sgbm_paths<NP, 2>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump);
         else
-            hipLaunchKernelGGL((k_sgbm_paths<NP, 4>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan);
+            hipLaunchKernelGGL((k_sgbm_paths<NP, 4>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump);
         VO_CHECK_LAUNCH(ctx);
     }
     {

@@ -157,7 +157,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->C, ctx->vol_cells);
     DALLOC(ctx->S, ctx->vol_cells * 5);   // one volume per MODE_SGBM path; grown to 8 for MODE_HH
     ctx->S_vols = 5;
-    DALLOC(ctx->disp_raw, npx); DALLOC(ctx->disp_tmp, npx);
+    DALLOC(ctx->disp_raw, npx); DALLOC(ctx->disp_tmp, npx); DALLOC(ctx->dump, 4096);
     DALLOC(ctx->ccl_label, npx); DALLOC(ctx->ccl_size, npx); DALLOC(ctx->ccl_runlen, npx);
     // ORB: 8-level pyramid is < 3.2x the base image
     ctx->pyr_bytes = npx * 4;
@@ -206,7 +206,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         if (f.ready) (void)hipEventDestroy(f.ready);
     }
     void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
-                   ctx->C, ctx->S, ctx->disp_raw, ctx->disp_tmp, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
+                   ctx->C, ctx->S, ctx->disp_raw, ctx->disp_tmp, ctx->dump, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
                    ctx->m_idx, ctx->m_dist, ctx->pts_a, ctx->pts_b, ctx->st_a, ctx->st_b, ctx->xy_a, ctx->xy_b,
                    ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws, ctx->ransac_ws };
     for (void* p : ps) if (p) (void)hipFree(p);

@@ -65,7 +65,7 @@ struct vo_ctx {
     // look-ahead engines (vo_prefetch_*): each has its own stream and staging; engine 0 shares the main
     // SGBM workspace, engines 1.. own an alternate one, so several pairs' SGBM can be in flight (one
     // pair's latency-bound kernels overlap another's bandwidth-bound ones)
-    static const int MAX_ENGINES = 4;
+    static const int MAX_ENGINES = 6;
     hipStream_t la_stream[MAX_ENGINES] = {};
     uint8_t* la_stage[MAX_ENGINES] = {};
     hipEvent_t sgbm_done = nullptr;  // end of the latest SGBM run in the CURRENT workspace (any stream)
@@ -84,7 +84,7 @@ struct vo_ctx {
     bool la_orb = false;
     int la_orb_params[4] = {0, 0, 0, 0};
     int32_t* slot_words = nullptr;   // pinned, one word per slot (keypoint counts of pending runs)
-    int n_engines = 3;               // VO_ENGINES
+    int n_engines = 6;               // VO_ENGINES
     int next_engine = 0;
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;
     std::string err;
@@ -117,6 +117,7 @@ struct vo_ctx {
     int S_vols = 0;                // path volumes allocated behind S
     int16_t* disp_raw = nullptr;
     int16_t* disp_tmp = nullptr;   // WTA output before the LR check
+    int16_t* dump = nullptr;       // sink for the stores of lanes past the end of their scan line
     int32_t* ccl_runlen = nullptr;
     int32_t* ccl_label = nullptr;
     int32_t* ccl_size = nullptr;

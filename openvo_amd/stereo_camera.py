@@ -65,7 +65,7 @@ class StereoCamera:
         self._slot_owner = [None] * _native.VO_NUM_SLOTS   # weak bookkeeping: FrameHandle per slot
         self._next_slot = 0
         # staged pairs: how many following pairs run their SGBM ahead (0..4; env VO_LOOKAHEAD overrides)
-        self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "3"))
+        self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "7"))
         self._lookahead = []         # [((index, preprocessed), slot, (w, h))] of the pairs in flight
         self._n_staged = 0
 
