@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvo355.so")
+LIB_PATH = os.environ.get("VO355_LIB") or os.path.join(_HERE, "libvo355.so")   # VO355_LIB: A/B another build of the same ABI
 _CSRC = os.path.join(_HERE, "csrc")
 
 VO_NUM_SLOTS = 10

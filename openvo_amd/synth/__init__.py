@@ -67,6 +67,17 @@ class Corridor:
         lib.vo_corridor_render_pair(ctypes.byref(self._cfg), int(k), left.ctypes.data, right.ctypes.data)
         return left, right
 
+    def pairs(self, first, n, threads=None):
+        """Frames first .. first+n-1, rendered on a few host threads (the renderer is pure C, re-entrant,
+        and ctypes drops the GIL around it)."""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        threads = threads or max(1, min(16, (os.cpu_count() or 2) // 2, n))
+        if threads == 1:
+            return [self.pair(first + i) for i in range(n)]
+        with ThreadPoolExecutor(threads) as ex:
+            return list(ex.map(self.pair, range(first, first + n)))
+
     # calibration of the ideal rig in the shapes StereoCamera takes
     def K(self):
         return np.array([[self.f, 0, self.cx], [0, self.f, self.cy], [0, 0, 1]], np.float64)
