@@ -73,6 +73,11 @@ int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
  * asynchronously; later calls that use the slot wait for it on the device.  Lets the next pair's
  * disparity overlap the current pair's ORB / matching / pose kernels. */
 int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
+/* the same from host images -- the caller's decode/ingest step in front of update():
+ * copied to pinned staging, uploaded asynchronously on the engine's stream, then as above.  The host
+ * buffers are free again when the call returns. */
+int vo_prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* left, const uint8_t* right, int w, int h,
+                     int channels, int preprocessed);
 /* look-ahead keypoints: when enabled, every vo_prefetch_staged_pair also runs the ORB extraction
  * (same arguments as vo_orb_detect_and_compute) behind the SGBM on the engine's stream; a later
  * vo_orb_detect_and_compute on that slot with the SAME arguments only waits and downloads, any

@@ -21,7 +21,7 @@ SYMBOLS = [
     "vo_create", "vo_destroy", "vo_last_error", "vo_device_name", "vo_synchronize",
     "vo_set_rectify_maps", "vo_set_sgbm", "vo_set_Q", "vo_set_roi", "vo_upload_pair",
     "vo_stage_pairs_alloc", "vo_stage_pair", "vo_load_staged_pair", "vo_prefetch_staged_pair",
-    "vo_set_lookahead_orb",
+    "vo_set_lookahead_orb", "vo_prefetch_pair",
     "vo_sgbm_compute", "vo_sgbm_compute_host", "vo_download_disparity_f32", "vo_download_xyz",
     "vo_download_left", "vo_download_right", "vo_cvt_bgr2gray", "vo_remap", "vo_reproject_to_3d",
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints",
@@ -80,6 +80,7 @@ def lib():
         L.vo_load_staged_pair.argtypes = [vp, ci, ci, ci]
         L.vo_prefetch_staged_pair.argtypes = [vp, ci, ci, ci]
         L.vo_set_lookahead_orb.argtypes = [vp, ci, ci, ci, ci, ci]
+        L.vo_prefetch_pair.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci]
         L.vo_sgbm_compute.argtypes = [vp, ci, vp]
         L.vo_sgbm_compute_host.argtypes = [vp, vp, vp, ci, ci, vp]
         for f in (L.vo_download_disparity_f32, L.vo_download_xyz, L.vo_download_left, L.vo_download_right):
@@ -178,6 +179,16 @@ class Context:
         left, right = _c(left, np.uint8), _c(right, np.uint8)
         h, w = left.shape[:2]
         self._ck(self._lib.vo_upload_pair(self._h, slot, _p(left), _p(right), w, h, ch, int(bool(preprocessed))))
+        return w, h
+
+    def prefetch_pair(self, slot, left, right, preprocessed):
+        """Look-ahead from host images: pinned staging + async upload + SGBM (+ ORB) on an engine."""
+        if left.shape != right.shape:
+            raise ValueError("left/right shapes differ")
+        ch = 3 if left.ndim == 3 else 1
+        left, right = _c(left, np.uint8), _c(right, np.uint8)
+        h, w = left.shape[:2]
+        self._ck(self._lib.vo_prefetch_pair(self._h, slot, _p(left), _p(right), w, h, ch, int(bool(preprocessed))))
         return w, h
 
     def stage_pairs(self, pairs):

@@ -222,6 +222,8 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         for (void* q : pa) if (q) (void)hipFree(q);
         if (a.done) (void)hipEventDestroy(a.done);
         orb_ws_free(a.orb);
+        if (a.pinned) (void)hipHostFree(a.pinned);
+        if (a.h2d_done) (void)hipEventDestroy(a.h2d_done);
         if (ctx->la_stream[k]) (void)hipStreamDestroy(ctx->la_stream[k]);
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -480,27 +482,42 @@ int slot_wait(vo_ctx* ctx, FrameSlot& f)
     return VO_OK;
 }
 
-// look-ahead: ingest + SGBM of a staged pair on the second stream.  The main stream keeps running
-// the previous pair's ORB / matching / pose meanwhile; consumers of the slot wait on its event.
-extern "C" int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed)
+// common tail of the look-ahead entry points: ingest (device or pinned-host source) + SGBM (+ ORB) of one
+// pair on the next engine's stream, `ready` recorded at the end
+static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8_t* srcR, bool from_host, int w, int h,
+                         int channels, int preprocessed)
 {
-    int rc = check_slot(ctx, slot);
-    if (rc) return rc;
-    if (index < 0 || index >= ctx->staged_n) return vo_fail(ctx, VO_E_ARG, "vo_prefetch_staged_pair: bad index");
-    if (!ctx->sg.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");
-    VO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
     FrameSlot& f = ctx->slots[slot];
-    const int w = ctx->staged_w, h = ctx->staged_h;
-    const size_t per = (size_t)w * h * ctx->staged_ch;
-    // alternate between the two look-ahead engines
     const int engine = ctx->next_engine;
     if ((rc = engine_prepare(ctx, engine))) return rc;
+    const size_t per = (size_t)w * h * channels;
+    hipMemcpyKind kind = hipMemcpyDeviceToDevice;
+    if (from_host) {
+        // user memory -> this engine's pinned buffer (plain memcpy) -> async H2D on the engine's stream;
+        // the buffer is reused only after the previous copy out of it has finished
+        vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
+        if (!a.pinned) {
+            VO_HIP(ctx, hipHostMalloc((void**)&a.pinned, ctx->stage_bytes * 2, hipHostMallocDefault));
+            VO_HIP(ctx, hipEventCreateWithFlags(&a.h2d_done, hipEventDisableTiming));
+        }
+        if (a.h2d_valid) VO_HIP(ctx, hipEventSynchronize(a.h2d_done));
+        memcpy(a.pinned, srcL, per);
+        memcpy(a.pinned + per, srcR, per);
+        srcL = a.pinned; srcR = a.pinned + per;
+        kind = hipMemcpyHostToDevice;
+    }
     ctx->next_engine = (engine + 1) % ctx->n_engines;
     engine_swap(ctx, engine);
     {
         StageTimer t(ctx, VO_T_UPLOAD);
-        rc = ingest(ctx, 0, ctx->staged + per * 2 * index, w, h, ctx->staged_ch, preprocessed, f.left, ctx->stage_in, hipMemcpyDeviceToDevice);
-        if (!rc) rc = ingest(ctx, 1, ctx->staged + per * (2 * index + 1), w, h, ctx->staged_ch, preprocessed, f.right, ctx->stage_in, hipMemcpyDeviceToDevice);
+        rc = ingest(ctx, 0, srcL, w, h, channels, preprocessed, f.left, ctx->stage_in, kind);
+        if (!rc) rc = ingest(ctx, 1, srcR, w, h, channels, preprocessed, f.right, ctx->stage_in, kind);
+    }
+    if (!rc && from_host) {
+        vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
+        if (hipEventRecord(a.h2d_done, ctx->stream) == hipSuccess) a.h2d_valid = true;
+        else rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
     }
     if (!rc) rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
     f.w = w; f.h = h; f.has_kp = false; f.n_kp = 0; f.kp_pending = false;
@@ -515,6 +532,34 @@ extern "C" int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int pre
     if (e != hipSuccess) return vo_fail(ctx, VO_E_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
     f.has_pair = true; f.has_disp = true; f.pending = true;
     return VO_OK;
+}
+
+// look-ahead: ingest + SGBM of a staged pair on an engine's stream.  The main stream keeps running
+// the current pair's ORB / matching / pose meanwhile; consumers of the slot wait for `ready`.
+extern "C" int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (index < 0 || index >= ctx->staged_n) return vo_fail(ctx, VO_E_ARG, "vo_prefetch_staged_pair: bad index");
+    if (!ctx->sg.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t per = (size_t)ctx->staged_w * ctx->staged_h * ctx->staged_ch;
+    return prefetch_pair(ctx, slot, ctx->staged + per * 2 * index, ctx->staged + per * (2 * index + 1), false, ctx->staged_w,
+                         ctx->staged_h, ctx->staged_ch, preprocessed);
+}
+
+// the same from host images (the user's decode/ingest step): the upload of pair i+k overlaps the work
+// on pair i; the host buffers are free again when the call returns
+extern "C" int vo_prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* left, const uint8_t* right, int w, int h, int channels,
+                                int preprocessed)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (!left || !right || (channels != 1 && channels != 3)) return vo_fail(ctx, VO_E_ARG, "vo_prefetch_pair: bad argument");
+    if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context %dx%d", w, h, ctx->max_w, ctx->max_h);
+    if (!ctx->sg.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    return prefetch_pair(ctx, slot, left, right, true, w, h, channels, preprocessed);
 }
 
 extern "C" int vo_set_lookahead_orb(vo_ctx* ctx, int enable, int nfeatures, int mask_mode, int min_disp16, int max_disp16)

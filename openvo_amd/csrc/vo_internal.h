@@ -79,6 +79,9 @@ struct vo_ctx {
         bool done_valid = false;
         bool ready = false;
         OrbWs orb;
+        uint8_t* pinned = nullptr;       // host staging of vo_prefetch_pair (two raw images)
+        hipEvent_t h2d_done = nullptr;   // the copies out of `pinned` have finished
+        bool h2d_valid = false;
     } ws_alt[MAX_ENGINES];           // [0] unused (engine 0 uses the main workspace)
     // ORB behind the look-ahead SGBM (vo_set_lookahead_orb): nfeatures, mask_mode, min/max disp16
     bool la_orb = false;

@@ -22,6 +22,15 @@ class StagedPair:
         self.index = int(index)
 
 
+class SubmittedPair:
+    """Handle of a host pair handed to StereoCamera.submit(): its upload, disparity (and, once the
+    odometer has announced its ORB settings, keypoints) already run on a look-ahead engine.  Pass it
+    as `img_left` (with img_right=None) to compute_3d / StereoOdometer.update."""
+
+    def __init__(self, slot, shape, preprocessed, images=None):
+        self.slot, self.shape, self.preprocessed, self.images = slot, shape, bool(preprocessed), images
+
+
 def _RESERVED():
     """Stand-in "owner" of a slot held by look-ahead work (callable like a weakref, never dead)."""
     return _RESERVED
@@ -96,7 +105,14 @@ class StereoCamera:
             self._slot_owner[s] = None
             return s, weakref
         # every slot is still referenced by user code: move the oldest frame to host memory
+        # (slots reserved by submit() hold work that cannot be redone and are never taken)
         s = self._next_slot
+        for k in range(n):
+            if self._slot_owner[(self._next_slot + k) % n] is not _RESERVED:
+                s = (self._next_slot + k) % n
+                break
+        else:
+            raise RuntimeError("every frame slot is held by a submitted pair")
         old = self._slot_owner[s]()
         if old is not None:
             old.evict()
@@ -113,6 +129,27 @@ class StereoCamera:
         self._lookahead = []
         self._n_staged = len(pairs)
         return [StagedPair(i) for i in range(len(pairs))]
+
+    def submit(self, img_left, img_right, preprocessed=False):
+        """Start upload + disparity (+ keypoints) of a host pair on a look-ahead engine and return a
+        SubmittedPair to hand to compute_3d / StereoOdometer.update later, in submission order.  The
+        arrays may be reused as soon as this returns.  Not in the reference: it is the ingest step a
+        caller puts in front of update() so that pair i+k uploads while pair i is being tracked.
+        With no free slot (more than VO_NUM_SLOTS - 3 pairs outstanding) the pair is kept on the host
+        and processed synchronously when consumed."""
+        img_left, img_right = np.asarray(img_left), np.asarray(img_right)
+        if img_left.ndim != img_right.ndim:
+            if img_left.ndim == 3:
+                img_left = self._ctx.cvt_bgr2gray(img_left)
+            if img_right.ndim == 3:
+                img_right = self._ctx.cvt_bgr2gray(img_right)
+        held = sum(1 for o in self._slot_owner if o is _RESERVED)
+        slot = self._free_slot() if held < _native.VO_NUM_SLOTS - 3 else None
+        if slot is None:
+            return SubmittedPair(None, None, preprocessed, (img_left.copy(), img_right.copy()))
+        shape = self._ctx.prefetch_pair(slot, img_left, img_right, preprocessed)
+        self._slot_owner[slot] = _RESERVED
+        return SubmittedPair(slot, shape, preprocessed)
 
     def reset_lookahead(self):
         """Drop look-ahead work that has been started but not consumed (its slots are released and
@@ -146,10 +183,20 @@ class StereoCamera:
     def compute_3d(self, img_left, img_right, preprocessed=False):
         """-> (img_3d float32 HcxWcx3, disparity float32 HcxWc, img_left uint8 HcxWc), cropped;
         each is a DeviceImage (np.asarray(x) or x[...] materialises it)."""
+        submitted = None
+        if isinstance(img_left, SubmittedPair):
+            submitted = img_left
+            if submitted.slot is None:                       # no slot was free at submit(): host copy
+                if submitted.images is None:
+                    raise ValueError("this SubmittedPair has already been consumed")
+                img_left, img_right = submitted.images
+                preprocessed = submitted.preprocessed
+                submitted.images = None
+                submitted = None
         staged = isinstance(img_left, StagedPair)
-        if not staged:
+        if not staged and submitted is None:
             img_left, img_right = np.asarray(img_left), np.asarray(img_right)
-        if not staged and img_left.ndim != img_right.ndim:
+        if not staged and submitted is None and img_left.ndim != img_right.ndim:
             # the reference converts each image independently (stereo_camera.py:44-47)
             if img_left.ndim == 3:
                 img_left = self._ctx.cvt_bgr2gray(img_left)
@@ -157,6 +204,11 @@ class StereoCamera:
                 img_right = self._ctx.cvt_bgr2gray(img_right)
         import weakref
         slot = None
+        if submitted is not None:
+            if self._slot_owner[submitted.slot] is not _RESERVED:
+                raise ValueError("this SubmittedPair has already been consumed")
+            slot, (w, h) = submitted.slot, submitted.shape
+            submitted.slot = None
         if staged:
             # was this pair already ingested + SGBM'd on the look-ahead stream?
             key = (img_left.index, bool(preprocessed))

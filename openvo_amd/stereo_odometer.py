@@ -112,6 +112,23 @@ class StereoOdometer:
         self.save_frame_update(next_img, next_disp, next_3d, next_kps, next_desc)
         return True
 
+    def run(self, pairs, depth=None):
+        """Feed an iterable of host (left, right) pairs through update(), keeping up to `depth` pairs
+        submitted ahead (StereoCamera.submit) so their upload and disparity overlap the tracking of
+        the current pair.  Yields update()'s result per pair, in order.  Not in the reference."""
+        from collections import deque
+        depth = int(self.stereo.lookahead if depth is None else depth)
+        it, queue = iter(pairs), deque()
+        while True:
+            while len(queue) <= depth:
+                nxt = next(it, None)
+                if nxt is None:
+                    break
+                queue.append(self.stereo.submit(nxt[0], nxt[1], preprocessed=self.preprocessed_frames))
+            if not queue:
+                return
+            yield self.update(queue.popleft(), None)
+
     _SEAMS = ("point_clouds", "point_cloud_transform", "rigid_body_filter", "bilinear_interpolate_pixels",
               "_estimate", "_gate")
 

@@ -223,3 +223,38 @@ def test_context_argument_errors():
     with pytest.raises(_native.VoError):
         ctx.sgbm_compute_host(np.zeros((256, 256), np.uint8), np.zeros((256, 256), np.uint8))   # exceeds max size
     ctx.close()
+
+
+@pytest.mark.parametrize("depth", [0, 3, 20])
+def test_submitted_host_pairs_equal_plain_updates(depth):
+    """SURVEY 8(f) row 3, the ingest step: pairs submitted ahead from host memory (pinned staging, async
+    upload, disparity and keypoints on the look-ahead engines) give bit-identical poses to plain
+    update(left, right) calls; depth 20 exceeds the frame slots and exercises the host fallback."""
+    c, cam = _rig("C1", max_keypoints=500)
+    frames = c.pairs(0, 14)
+    kw = dict(preprocessed_frames=True, rigidity_threshold=0.1, outlier_threshold=0.02)
+    plain = StereoOdometer(cam, **kw)
+    want = []
+    for L, R in frames:
+        ok = plain.update(L, R)
+        want.append((ok, plain.c_T_w.copy()))
+    odo = StereoOdometer(cam, **kw)
+    got = []
+    scratch = [np.empty_like(frames[0][0]), np.empty_like(frames[0][1])]
+
+    def feed():   # the caller may reuse its buffers as soon as submit() returns
+        for L, R in frames:
+            scratch[0][...] = L
+            scratch[1][...] = R
+            yield scratch[0], scratch[1]
+
+    for ok in odo.run(feed(), depth=depth):
+        got.append((ok, odo.c_T_w.copy()))
+    assert len(got) == len(want)
+    for (a, Ta), (b, Tb) in zip(got, want):
+        assert a == b and np.array_equal(Ta, Tb)
+    # a consumed handle cannot be used twice
+    h = cam.submit(*frames[0], preprocessed=True)
+    cam.compute_3d(h, None)
+    with pytest.raises(ValueError):
+        cam.compute_3d(h, None)
