@@ -174,6 +174,18 @@ int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, int n
                         float thr, uint32_t seed, double* E9_out, uint8_t* mask_out, int32_t* counts_out,
                         int32_t* best2_out);
 
+/* RANSAC solvePnP hypothesis scoring (north star; BASELINE config 2 names "ORB+SGBM+PnP") ----------
+ * NOT part of the reference either (openVO fits 3-D/3-D, stereo_odometer.py:187-205): defined by this
+ * build.  iters hypotheses; each draws 4 correspondences (same hash RNG), solves P3P on three of them in
+ * float64 and lets the fourth pick among the <= 4 poses; P = K [R|t] in float32; a point is an inlier iff
+ * it is in front of the camera and its reprojection error is below thr pixels (division-free float32
+ * test), counted with wavefront ballot + popcount.  pts3d: n x 3 float32 (frame of the first view),
+ * pts2d: n x 2 float32 pixels in the second view.  Rt12_out: row-major 3x4 world-to-camera pose of the
+ * winner (ties -> lowest hypothesis index; all zeros if no hypothesis produced a pose). */
+int vo_ransac_pnp(vo_ctx* ctx, const float* pts3d, const float* pts2d, int n, const double* K4, int iters,
+                  float thr, uint32_t seed, double* Rt12_out, uint8_t* mask_out, int32_t* counts_out,
+                  int32_t* best2_out);
+
 /* instrumentation ------------------------------------------------------------------------ */
 /* hipEvent timing of the kernels launched on the context stream (events are recorded without
  * blocking and resolved by vo_get_timings).  Stage ids: */

@@ -26,7 +26,7 @@ SYMBOLS = [
     "vo_download_left", "vo_download_right", "vo_cvt_bgr2gray", "vo_remap", "vo_reproject_to_3d",
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
-    "vo_pose_pair", "vo_ransac_essential", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
+    "vo_pose_pair", "vo_ransac_essential", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
     "vo_sgbm_last_geometry",
 ]
 
@@ -98,6 +98,7 @@ def lib():
         L.vo_point_clouds.argtypes = [vp, ci, ci, cd, vp, vp, vp, vp, vp, vp, ci, vp]
         L.vo_pose_pair.argtypes = [vp, ci, ci, cd, ci, cd, cd, vp, vp, vp, vp]
         L.vo_ransac_essential.argtypes = [vp, vp, vp, ci, vp, ci, ctypes.c_float, ctypes.c_uint32, vp, vp, vp, vp]
+        L.vo_ransac_pnp.argtypes = [vp, vp, vp, ci, vp, ci, ctypes.c_float, ctypes.c_uint32, vp, vp, vp, vp]
         L.vo_umeyama.argtypes = [vp, vp, vp, ci, ci, vp, vp]
         L.vo_rigid_clique.argtypes = [vp, vp, vp, ci, cd, vp]
         L.vo_rodrigues.argtypes = [vp, vp]
@@ -377,6 +378,20 @@ class Context:
         self._ck(self._lib.vo_ransac_essential(self._h, _p(pts1), _p(pts2), n, _p(K4), int(iters), float(thr), int(seed),
                                                _p(E), _p(mask), _p(counts), _p(best)))
         return dict(E=E.reshape(3, 3), mask=mask, counts=counts, best_iter=int(best[0]), best_count=int(best[1]))
+
+    def ransac_pnp(self, pts3d, pts2d, K4, iters=5000, thr=2.0, seed=4321, want_counts=False):
+        pts3d, pts2d = _c(pts3d, np.float32).reshape(-1, 3), _c(pts2d, np.float32).reshape(-1, 2)
+        if len(pts3d) != len(pts2d):
+            raise ValueError("point sets differ in length")
+        K4 = _c(K4, np.float64)
+        n = len(pts3d)
+        Rt = np.zeros(12, np.float64)
+        mask = np.zeros(n, np.uint8)
+        counts = np.zeros(iters, np.int32) if want_counts else None
+        best = np.zeros(2, np.int32)
+        self._ck(self._lib.vo_ransac_pnp(self._h, _p(pts3d), _p(pts2d), n, _p(K4), int(iters), float(thr), int(seed),
+                                         _p(Rt), _p(mask), _p(counts), _p(best)))
+        return dict(Rt=Rt.reshape(3, 4), mask=mask, counts=counts, best_iter=int(best[0]), best_count=int(best[1]))
 
     def umeyama(self, src, dst, force_rotation=True):
         src, dst = _c(src, np.float32).reshape(-1, 3), _c(dst, np.float32).reshape(-1, 3)

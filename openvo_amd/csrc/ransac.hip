@@ -263,3 +263,326 @@ extern "C" int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* 
     VO_HIP(ctx, hipMemcpy(E9_out, d_E + (size_t)best2_out[0] * 9, 72, hipMemcpyDeviceToHost));
     return VO_OK;
 }
+
+// =========================================================================================
+// RANSAC solvePnP hypothesis generation + reprojection scoring (the north star's "solvePnP
+// hypothesis-scoring loop").  No openVO counterpart either; same structure as above:
+//   k_pnp_hyp     one lane per hypothesis: 4 hash-sampled correspondences, P3P on three of them in
+//                 float64 (depths along the bearings; singular member of the two-conic pencil by a
+//                 bisected cubic root -- only + - * / sqrt; <= 4 poses, Gauss-Newton polish), the fourth
+//                 picks the pose; P = K [R|t] rounded to float32
+//   k_pnp_score   one wave per hypothesis; division-free reprojection test in float32
+//                 ((xc - u zc)^2 + (yc - v zc)^2 < thr^2 zc^2, zc > 0), ballot + popcount
+// =========================================================================================
+__device__ __forceinline__ double pn_det3(const double m[3][3])
+{
+    return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+           m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+
+__device__ double pn_det3_col(const double A[3][3], const double B[3][3], int c)
+{
+    double m[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] = j == c ? B[i][j] : A[i][j];
+    return pn_det3(m);
+}
+
+__device__ __forceinline__ double pn_cubic(const double* c, double g) { return ((c[3] * g + c[2]) * g + c[1]) * g + c[0]; }
+
+__device__ double pn_cubic_root(const double* c)
+{
+    double m = fabs(c[2]);
+    if (fabs(c[1]) > m) m = fabs(c[1]);
+    if (fabs(c[0]) > m) m = fabs(c[0]);
+    double hi = 1.0 + m / fabs(c[3]), lo = -hi;
+    double flo = pn_cubic(c, lo);
+    for (int it = 0; it < 80; it++) {
+        const double mid = 0.5 * (lo + hi), fm = pn_cubic(c, mid);
+        if ((fm < 0.0) == (flo < 0.0)) { lo = mid; flo = fm; } else hi = mid;
+    }
+    double g = 0.5 * (lo + hi);
+    for (int it = 0; it < 2; it++) {
+        const double d = (3.0 * c[3] * g + 2.0 * c[2]) * g + c[1];
+        if (d != 0.0) g -= pn_cubic(c, g) / d;
+    }
+    return g;
+}
+
+__device__ bool pn_null_vec(const double M[3][3], double s, double* e)
+{
+    double r[3][3], c[3][3], best = -1.0;
+    int bi = 0;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[i][j] = M[i][j] - (i == j ? s : 0.0);
+    rs_cross3(r[0], r[1], c[0]);
+    rs_cross3(r[0], r[2], c[1]);
+    rs_cross3(r[1], r[2], c[2]);
+    for (int k = 0; k < 3; k++) {
+        const double n2 = c[k][0] * c[k][0] + c[k][1] * c[k][1] + c[k][2] * c[k][2];
+        if (n2 > best) { best = n2; bi = k; }
+    }
+    if (!(best > 0.0)) return false;
+    const double inv = 1.0 / sqrt(best);
+    for (int k = 0; k < 3; k++) e[k] = c[bi][k] * inv;
+    return true;
+}
+
+// y: 3 unit bearings, x: 3 points (rows); Rs/ts receive up to 4 poses
+__device__ int pn_p3p(const double* y, const double* x, double* Rs, double* ts)
+{
+    const double *y1 = y, *y2 = y + 3, *y3 = y + 6, *x1 = x, *x2 = x + 3, *x3 = x + 6;
+    const double b12 = y1[0] * y2[0] + y1[1] * y2[1] + y1[2] * y2[2];
+    const double b13 = y1[0] * y3[0] + y1[1] * y3[1] + y1[2] * y3[2];
+    const double b23 = y2[0] * y3[0] + y2[1] * y3[1] + y2[2] * y3[2];
+    double d12[3], d13[3], d23[3], dx[3];
+    for (int k = 0; k < 3; k++) { d12[k] = x1[k] - x2[k]; d13[k] = x1[k] - x3[k]; d23[k] = x2[k] - x3[k]; }
+    const double a12 = d12[0] * d12[0] + d12[1] * d12[1] + d12[2] * d12[2];
+    const double a13 = d13[0] * d13[0] + d13[1] * d13[1] + d13[2] * d13[2];
+    const double a23 = d23[0] * d23[0] + d23[1] * d23[1] + d23[2] * d23[2];
+    rs_cross3(d12, d13, dx);
+    const double area2 = dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2];
+    if (!(a12 > 0.0) || !(a13 > 0.0) || !(a23 > 0.0) || !(area2 > 1e-24 * a12 * a13)) return 0;
+
+    const double D1[3][3] = { { a23, -a23 * b12, 0.0 }, { -a23 * b12, a23 - a12, a12 * b23 }, { 0.0, a12 * b23, -a12 } };
+    const double D2[3][3] = { { a23, 0.0, -a23 * b13 }, { 0.0, -a13, a13 * b23 }, { -a23 * b13, a13 * b23, a23 - a13 } };
+    double c[4];
+    c[0] = pn_det3(D1);
+    c[3] = pn_det3(D2);
+    c[1] = (pn_det3_col(D1, D2, 0) + pn_det3_col(D1, D2, 1)) + pn_det3_col(D1, D2, 2);
+    c[2] = (pn_det3_col(D2, D1, 0) + pn_det3_col(D2, D1, 1)) + pn_det3_col(D2, D1, 2);
+    double D0[3][3];
+    if (fabs(c[3]) >= fabs(c[0])) {
+        if (c[3] == 0.0) return 0;
+        const double g = pn_cubic_root(c);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) D0[i][j] = D1[i][j] + g * D2[i][j];
+    } else {
+        const double cr[4] = { c[3], c[2], c[1], c[0] };
+        const double g = pn_cubic_root(cr);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) D0[i][j] = g * D1[i][j] + D2[i][j];
+    }
+    const double tr = (D0[0][0] + D0[1][1]) + D0[2][2];
+    const double m2 = ((D0[0][0] * D0[1][1] - D0[0][1] * D0[0][1]) + (D0[0][0] * D0[2][2] - D0[0][2] * D0[0][2])) +
+                      (D0[1][1] * D0[2][2] - D0[1][2] * D0[1][2]);
+    if (!(m2 < 0.0)) return 0;
+    const double disc = tr * tr - 4.0 * m2;
+    const double s1 = 0.5 * (tr + (tr >= 0.0 ? 1.0 : -1.0) * sqrt(disc));
+    const double s2 = m2 / s1;
+    double e1[3], e2[3];
+    if (!pn_null_vec(D0, s1, e1) || !pn_null_vec(D0, s2, e2)) return 0;
+    const double s = sqrt(-s2 / s1);
+
+    int ns = 0;
+    for (int sg = 0; sg < 2; sg++) {
+        double p[3];
+        for (int k = 0; k < 3; k++) p[k] = e1[k] + (sg ? -s : s) * e2[k];
+        if (!(fabs(p[0]) > 1e-12)) continue;
+        const double w0 = -p[1] / p[0], w1 = -p[2] / p[0];
+        const double A = a23 * w1 * w1 - a12;
+        const double B = (2.0 * a23 * w0 * w1 - 2.0 * a23 * b12 * w1) + 2.0 * a12 * b23;
+        const double C = ((a23 * w0 * w0 - 2.0 * a23 * b12 * w0) + a23) - a12;
+        double tau[2];
+        int nt = 0;
+        if (fabs(A) > 1e-14 * (fabs(B) + fabs(C))) {
+            const double dq = B * B - 4.0 * A * C;
+            if (dq >= 0.0) {
+                const double sq = sqrt(dq);
+                tau[0] = (-B + sq) / (2.0 * A);
+                tau[1] = (-B - sq) / (2.0 * A);
+                nt = 2;
+            }
+        } else if (B != 0.0) {
+            tau[0] = -C / B;
+            nt = 1;
+        }
+        for (int q = 0; q < nt; q++) {
+            const double t = tau[q];
+            if (!(t > 0.0)) continue;
+            const double den = (1.0 + t * t) - 2.0 * b23 * t;
+            if (!(den > 0.0)) continue;
+            double l2 = sqrt(a23 / den), l3 = t * l2, l1 = (w0 + w1 * t) * l2;
+            if (!(l1 > 0.0)) continue;
+            for (int it = 0; it < 3; it++) {
+                const double r0 = ((l1 * l1 + l2 * l2) - 2.0 * b12 * l1 * l2) - a12;
+                const double r1 = ((l1 * l1 + l3 * l3) - 2.0 * b13 * l1 * l3) - a13;
+                const double r2 = ((l2 * l2 + l3 * l3) - 2.0 * b23 * l2 * l3) - a23;
+                const double J[3][3] = { { 2.0 * l1 - 2.0 * b12 * l2, 2.0 * l2 - 2.0 * b12 * l1, 0.0 },
+                                         { 2.0 * l1 - 2.0 * b13 * l3, 0.0, 2.0 * l3 - 2.0 * b13 * l1 },
+                                         { 0.0, 2.0 * l2 - 2.0 * b23 * l3, 2.0 * l3 - 2.0 * b23 * l2 } };
+                const double dj = pn_det3(J);
+                if (dj == 0.0) break;
+                const double rr[3][3] = { { r0, r0, r0 }, { r1, r1, r1 }, { r2, r2, r2 } };
+                const double n0 = pn_det3_col(J, rr, 0), n1 = pn_det3_col(J, rr, 1), n2 = pn_det3_col(J, rr, 2);
+                l1 -= n0 / dj; l2 -= n1 / dj; l3 -= n2 / dj;
+            }
+            if (!(l1 > 0.0) || !(l2 > 0.0) || !(l3 > 0.0)) continue;
+            double ya[3], yb[3], yc[3];
+            for (int k = 0; k < 3; k++) { ya[k] = l1 * y1[k] - l2 * y2[k]; yb[k] = l1 * y1[k] - l3 * y3[k]; }
+            rs_cross3(ya, yb, yc);
+            const double X[3][3] = { { d12[0], d13[0], dx[0] }, { d12[1], d13[1], dx[1] }, { d12[2], d13[2], dx[2] } };
+            const double dX = pn_det3(X);
+            if (dX == 0.0) continue;
+            double Xi[3][3];
+            Xi[0][0] = (X[1][1] * X[2][2] - X[1][2] * X[2][1]) / dX;
+            Xi[0][1] = (X[0][2] * X[2][1] - X[0][1] * X[2][2]) / dX;
+            Xi[0][2] = (X[0][1] * X[1][2] - X[0][2] * X[1][1]) / dX;
+            Xi[1][0] = (X[1][2] * X[2][0] - X[1][0] * X[2][2]) / dX;
+            Xi[1][1] = (X[0][0] * X[2][2] - X[0][2] * X[2][0]) / dX;
+            Xi[1][2] = (X[0][2] * X[1][0] - X[0][0] * X[1][2]) / dX;
+            Xi[2][0] = (X[1][0] * X[2][1] - X[1][1] * X[2][0]) / dX;
+            Xi[2][1] = (X[0][1] * X[2][0] - X[0][0] * X[2][1]) / dX;
+            Xi[2][2] = (X[0][0] * X[1][1] - X[0][1] * X[1][0]) / dX;
+            double* R = Rs + 9 * ns;
+            double* tt = ts + 3 * ns;
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) R[i * 3 + j] = (ya[i] * Xi[0][j] + yb[i] * Xi[1][j]) + yc[i] * Xi[2][j];
+            for (int i = 0; i < 3; i++) tt[i] = l1 * y1[i] - ((R[i * 3] * x1[0] + R[i * 3 + 1] * x1[1]) + R[i * 3 + 2] * x1[2]);
+            ns++;
+        }
+    }
+    return ns;
+}
+
+__global__ void __launch_bounds__(64) k_pnp_hyp(const float* __restrict__ X, const float* __restrict__ uv, int n, K4 K, int iters,
+                                                uint32_t seed, double* __restrict__ Rt_out, float* __restrict__ P_out)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= iters) return;
+    int idx[4];
+    for (int j = 0; j < 4; j++) {
+        uint32_t attempt = 0;
+        for (;;) {
+            uint32_t r = lowbias32(seed ^ lowbias32((uint32_t)h * 0x9E3779B9u + (uint32_t)j * 0x85EBCA6Bu + attempt * 0xC2B2AE35u));
+            int cand = (int)(r % (uint32_t)n), dup = 0;
+            for (int k = 0; k < j; k++) dup |= idx[k] == cand;
+            if (!dup || attempt >= 64) { idx[j] = cand; break; }
+            attempt++;
+        }
+    }
+    double y[9], x[9], Rs[36], ts[12];
+    for (int s = 0; s < 3; s++) {
+        const int i = idx[s];
+        const double a = ((double)uv[2 * i] - K.cx) / K.fx, b = ((double)uv[2 * i + 1] - K.cy) / K.fy;
+        const double inv = 1.0 / sqrt((a * a + b * b) + 1.0);
+        y[3 * s] = a * inv; y[3 * s + 1] = b * inv; y[3 * s + 2] = inv;
+        for (int k = 0; k < 3; k++) x[3 * s + k] = (double)X[3 * i + k];
+    }
+    const int ns = pn_p3p(y, x, Rs, ts);
+    const int i4 = idx[3];
+    const double u4 = ((double)uv[2 * i4] - K.cx) / K.fx, v4 = ((double)uv[2 * i4 + 1] - K.cy) / K.fy;
+    const double x4[3] = { (double)X[3 * i4], (double)X[3 * i4 + 1], (double)X[3 * i4 + 2] };
+    int best = -1;
+    double beste = 0.0;
+    for (int s = 0; s < ns; s++) {
+        const double* R = Rs + 9 * s;
+        const double* t = ts + 3 * s;
+        const double xc = ((R[0] * x4[0] + R[1] * x4[1]) + R[2] * x4[2]) + t[0];
+        const double yc = ((R[3] * x4[0] + R[4] * x4[1]) + R[5] * x4[2]) + t[1];
+        const double zc = ((R[6] * x4[0] + R[7] * x4[1]) + R[8] * x4[2]) + t[2];
+        if (!(zc > 0.0)) continue;
+        const double du = xc / zc - u4, dv = yc / zc - v4, e = du * du + dv * dv;
+        if (best < 0 || e < beste) { best = s; beste = e; }
+    }
+    double Rt[12];
+    float P[12];
+    if (best < 0) {
+        for (int k = 0; k < 12; k++) { Rt[k] = 0.0; P[k] = 0.0f; }
+    } else {
+        const double* R = Rs + 9 * best;
+        const double* t = ts + 3 * best;
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rt[r * 4 + c] = R[r * 3 + c]; Rt[r * 4 + 3] = t[r]; }
+        for (int c = 0; c < 4; c++) {
+            P[c] = (float)(K.fx * Rt[c] + K.cx * Rt[8 + c]);
+            P[4 + c] = (float)(K.fy * Rt[4 + c] + K.cy * Rt[8 + c]);
+            P[8 + c] = (float)Rt[8 + c];
+        }
+    }
+    for (int k = 0; k < 12; k++) { Rt_out[(size_t)h * 12 + k] = Rt[k]; P_out[(size_t)h * 12 + k] = P[k]; }
+}
+
+__device__ __forceinline__ bool reproj_inlier(const float* P, float X, float Y, float Z, float u, float v, float thr2)
+{
+    const float xc = ((P[0] * X + P[1] * Y) + P[2] * Z) + P[3];
+    const float yc = ((P[4] * X + P[5] * Y) + P[6] * Z) + P[7];
+    const float zc = ((P[8] * X + P[9] * Y) + P[10] * Z) + P[11];
+    const float du = xc - u * zc, dv = yc - v * zc;
+    const float e = du * du + dv * dv;
+    const float lim = thr2 * (zc * zc);
+    return zc > 0.0f && e < lim;
+}
+
+// one wave per hypothesis
+__global__ void __launch_bounds__(256) k_pnp_score(const float* __restrict__ X, const float* __restrict__ uv, int n,
+                                                  const float* __restrict__ P_all, int iters, float thr2, int32_t* __restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (h >= iters) return;
+    float P[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) P[k] = P_all[(size_t)h * 12 + k];
+    int cnt = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false;
+        if (i < n) {
+            const float2 b = ((const float2*)uv)[i];
+            in = reproj_inlier(P, X[3 * i], X[3 * i + 1], X[3 * i + 2], b.x, b.y, thr2);
+        }
+        cnt += __popcll(__ballot(in));
+    }
+    if (lane == 0) counts[h] = cnt;
+}
+
+__global__ void k_pnp_mask(const float* __restrict__ X, const float* __restrict__ uv, int n, const float* __restrict__ P_all,
+                           const int32_t* __restrict__ best, float thr2, uint8_t* __restrict__ mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float P[12];
+    for (int k = 0; k < 12; k++) P[k] = P_all[(size_t)best[0] * 12 + k];
+    const float2 b = ((const float2*)uv)[i];
+    mask[i] = reproj_inlier(P, X[3 * i], X[3 * i + 1], X[3 * i + 2], b.x, b.y, thr2) ? 1 : 0;
+}
+
+extern "C" int vo_ransac_pnp(vo_ctx* ctx, const float* pts3d, const float* pts2d, int n, const double* K4v, int iters, float thr,
+                             uint32_t seed, double* Rt12_out, uint8_t* mask_out, int32_t* counts_out, int32_t* best2_out)
+{
+    if (!ctx || !pts3d || !pts2d || !K4v || !Rt12_out || !best2_out) return vo_fail(ctx, VO_E_ARG, "vo_ransac_pnp: bad argument");
+    if (n < 4 || iters <= 0 || iters > (1 << 22) || n > (1 << 24)) return vo_fail(ctx, VO_E_ARG, "vo_ransac_pnp: need n >= 4 and 0 < iters <= 4194304");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    // workspace: Rt (iters x 96 B), points (n x 12 B + n x 8 B), P (iters x 48 B), counts, best, mask
+    const size_t need = (size_t)n * 24 + (size_t)iters * (96 + 48 + 4) + (size_t)n + 4096;
+    if (ctx->ransac_ws_bytes < need) {
+        if (ctx->ransac_ws) (void)hipFree(ctx->ransac_ws);
+        ctx->ransac_ws = nullptr; ctx->ransac_ws_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->ransac_ws, need));
+        ctx->ransac_ws_bytes = need;
+    }
+    uint8_t* w = ctx->ransac_ws;
+    double* d_Rt = (double*)w; w += (size_t)iters * 96;
+    float* d_uv = (float*)w; w += (size_t)n * 8;
+    float* d_X = (float*)w; w += (size_t)n * 12 + 8;
+    w = (uint8_t*)(((uintptr_t)w + 15) & ~(uintptr_t)15);
+    float* d_P = (float*)w; w += (size_t)iters * 48;
+    int32_t* d_counts = (int32_t*)w; w += (size_t)iters * 4;
+    int32_t* d_best = (int32_t*)w; w += 256;
+    uint8_t* d_mask = w;
+    StageTimer t(ctx, VO_T_POSE);
+    int rc = xfer_h2d(ctx, d_X, pts3d, (size_t)n * 12);
+    if (!rc) rc = xfer_h2d(ctx, d_uv, pts2d, (size_t)n * 8);
+    if (rc) return rc;
+    const K4 K{ K4v[0], K4v[1], K4v[2], K4v[3] };
+    const float thr2 = thr * thr;
+    hipLaunchKernelGGL(k_pnp_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, d_X, d_uv, n, K, iters, seed, d_Rt, d_P);
+    hipLaunchKernelGGL(k_pnp_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, d_X, d_uv, n, d_P, iters, thr2, d_counts);
+    hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(1024), 0, ctx->stream, d_counts, iters, d_best);
+    hipLaunchKernelGGL(k_pnp_mask, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_X, d_uv, n, d_P, d_best, thr2, d_mask);
+    VO_CHECK_LAUNCH(ctx);
+    VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask_out && (rc = xfer_d2h(ctx, mask_out, d_mask, (size_t)n))) return rc;
+    if (counts_out && (rc = xfer_d2h(ctx, counts_out, d_counts, (size_t)iters * 4))) return rc;
+    if ((rc = xfer_flush(ctx))) return rc;
+    best2_out[0] = ((int32_t*)ctx->pinned)[0];
+    best2_out[1] = ((int32_t*)ctx->pinned)[1];
+    VO_HIP(ctx, hipMemcpy(Rt12_out, d_Rt + (size_t)best2_out[0] * 12, 96, hipMemcpyDeviceToHost));
+    return VO_OK;
+}

@@ -1,4 +1,4 @@
-"""RANSAC essential-matrix estimation on the GPU (BASELINE config 5).
+"""RANSAC essential-matrix (BASELINE config 5) and solvePnP estimation on the GPU.
 
 Not part of openVO -- the reference fits its pose in closed form.  Provided as an
 extra, with its own CPU restatement for parity; `StereoOdometer` never calls it.
@@ -22,3 +22,19 @@ def find_essential_mat(points1, points2, K, iters=5000, threshold=1.0, seed=4321
         if own:
             ctx.close()
     return r["E"], r["mask"], dict(best_iter=r["best_iter"], best_count=r["best_count"])
+
+
+def solve_pnp_ransac(points3d, points2d, K, iters=5000, threshold=2.0, seed=4321, context=None):
+    """points3d: (n, 3) points in the first view's frame; points2d: (n, 2) pixel positions of the same
+    features in the second view; K: 3x3 intrinsics.  Returns (R 3x3, t 3, inlier mask uint8 (n,), info).
+    Hypotheses: P3P on hash-sampled minimal sets, a fourth sample disambiguating; the winner has the most
+    points reprojecting within `threshold` pixels, ties going to the earliest hypothesis.  x_cam = R X + t."""
+    K = np.asarray(K, np.float64)
+    own = context is None
+    ctx = context or _native.Context(0, 64, 64, 16, 64)
+    try:
+        r = ctx.ransac_pnp(points3d, points2d, [K[0, 0], K[1, 1], K[0, 2], K[1, 2]], iters, threshold, seed)
+    finally:
+        if own:
+            ctx.close()
+    return r["Rt"][:, :3].copy(), r["Rt"][:, 3].copy(), r["mask"], dict(best_iter=r["best_iter"], best_count=r["best_count"])

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libvo_oracle.so")
-_SRC = ["src/sgbm.c", "src/imgproc.c", "src/orb.c", "src/match.c", "src/geom.c", "src/ransac.c", "vo_oracle.h"]
+_SRC = ["src/sgbm.c", "src/imgproc.c", "src/orb.c", "src/match.c", "src/geom.c", "src/ransac.c", "src/pnp.c", "vo_oracle.h"]
 
 
 def build_oracle(force=False):
@@ -245,3 +245,34 @@ def ransac_essential(p1, p2, K4, iters=5000, thr=1.0, seed=4321):
     if best < 0:
         raise ValueError("ransac_essential needs at least 8 correspondences")
     return dict(E=E.reshape(3, 3), mask=mask, counts=counts, best_iter=bi.value, best_count=best)
+
+
+def p3p(bearings, points):
+    """3 unit bearings + 3 points -> list of (R 3x3, t 3) candidate poses (<= 4)"""
+    y, x = _c(bearings, np.float64).reshape(3, 3), _c(points, np.float64).reshape(3, 3)
+    R, t = np.zeros(36), np.zeros(12)
+    f = lib().vo_ref_p3p
+    f.argtypes = [ctypes.c_void_p] * 4
+    f.restype = ctypes.c_int
+    n = f(_p(y), _p(x), _p(R), _p(t))
+    return [(R[9 * k:9 * k + 9].reshape(3, 3).copy(), t[3 * k:3 * k + 3].copy()) for k in range(n)]
+
+
+def ransac_pnp(pts3d, pts2d, K4, iters=5000, thr=2.0, seed=4321):
+    """-> dict(Rt 3x4, mask uint8 n, counts int32 iters, best_iter, best_count)"""
+    X, uv, K4 = _c(pts3d, np.float32).reshape(-1, 3), _c(pts2d, np.float32).reshape(-1, 2), _c(K4, np.float64)
+    n = len(X)
+    if len(uv) != n:
+        raise ValueError("pts3d / pts2d lengths differ")
+    Rt = np.zeros(12, np.float64)
+    mask = np.zeros(n, np.uint8)
+    counts = np.zeros(iters, np.int32)
+    bi = ctypes.c_int(-1)
+    f = lib().vo_ref_ransac_pnp
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                  ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    f.restype = ctypes.c_int
+    best = f(_p(X), _p(uv), n, _p(K4), int(iters), float(thr), int(seed), _p(Rt), _p(mask), _p(counts), ctypes.byref(bi))
+    if best < 0:
+        raise ValueError("ransac_pnp needs at least 4 correspondences")
+    return dict(Rt=Rt.reshape(3, 4), mask=mask, counts=counts, best_iter=bi.value, best_count=best)

@@ -112,6 +112,15 @@ int vo_ref_sampson_count(const float* F9, const float* p1, const float* p2, int 
 int vo_ref_ransac_essential(const float* p1, const float* p2, int n, const double* K4, int iters, float thr,
                             uint32_t seed, double* E_best9, uint8_t* mask, int32_t* counts, int* best_iter);
 
+/* ---- RANSAC solvePnP hypothesis scoring (north star; no openVO counterpart) -------------------- */
+void vo_ref_ransac_sample4(uint32_t seed, int h, int n, int* idx4);
+/* y: 3 unit bearings, x: 3 points (rows) -> number of poses (<= 4), R (row-major 9 each), t (3 each) */
+int vo_ref_p3p(const double* y9, const double* x9, double* R36, double* t12);
+int vo_ref_pnp_hypothesis(const float* X, const float* uv, const int* idx4, const double* K4, double* Rt12, float* P12);
+int vo_ref_reproj_count(const float* P12, const float* X, const float* uv, int n, float thr, uint8_t* mask);
+int vo_ref_ransac_pnp(const float* X, const float* uv, int n, const double* K4, int iters, float thr, uint32_t seed,
+                      double* Rt_best12, uint8_t* mask, int32_t* counts, int* best_iter);
+
 #ifdef __cplusplus
 }
 #endif

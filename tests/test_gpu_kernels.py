@@ -184,3 +184,47 @@ def test_ransac_essential_bit_exact(oracle, ctx_small, n, iters):
         assert min(np.abs(E - Et).max(), np.abs(E + Et).max()) < 0.06   # sanity of the estimator, not a parity bar
         inl = np.setdiff1d(np.arange(n), out)
         assert got["mask"][inl].mean() > 0.95 and got["mask"][out].mean() < 0.1
+
+
+def _pnp_scene(n, seed, outlier_frac=0.3, noise=0.3):
+    rng = np.random.default_rng(seed)
+    f, cx, cy = 718.856, 640.0, 360.0
+    X = np.stack([rng.uniform(-8, 8, n), rng.uniform(-3, 3, n), rng.uniform(4, 40, n)], 1)
+    r = np.array([0.01, -0.03, 0.005])
+    th = np.linalg.norm(r)
+    k = r / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    t = np.array([0.05, -0.02, -0.3])
+    Xc = X @ R.T + t
+    uv = np.stack([f * Xc[:, 0] / Xc[:, 2] + cx, f * Xc[:, 1] / Xc[:, 2] + cy], 1) + rng.normal(0, noise, (n, 2))
+    out = rng.choice(n, int(n * outlier_frac), replace=False)
+    uv[out] += rng.uniform(-60, 60, size=(len(out), 2))
+    return X.astype(np.float32), uv.astype(np.float32), [f, f, cx, cy], R, t, out
+
+
+@pytest.mark.parametrize("n,iters", [(500, 400), (4, 8), (8000, 300), (61, 1000)])
+def test_ransac_pnp_bit_exact(oracle, ctx_small, n, iters):
+    """No openVO counterpart: GPU vs the build's own CPU restatement -- every hypothesis' inlier count,
+    the winner and its mask identical, the pose to 1e-12 (same IEEE operations in the same order)."""
+    X, uv, K4, R, t, out = _pnp_scene(n, 100 + n + iters)
+    ref = oracle.ransac_pnp(X, uv, K4, iters, 2.0, 4321)
+    got = ctx_small.ransac_pnp(X, uv, K4, iters, 2.0, 4321, want_counts=True)
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert got["best_iter"] == ref["best_iter"] and got["best_count"] == ref["best_count"]
+    assert np.array_equal(got["mask"], ref["mask"])
+    assert np.allclose(got["Rt"], ref["Rt"], rtol=0, atol=1e-12)
+    if n >= 500:
+        assert np.abs(got["Rt"][:, :3] - R).max() < 5e-3 and np.abs(got["Rt"][:, 3] - t).max() < 5e-2   # estimator sanity
+        inl = np.setdiff1d(np.arange(n), out)
+        assert got["mask"][inl].mean() > 0.9 and got["mask"][out].mean() < 0.1
+
+
+def test_solve_pnp_ransac_wrapper(ctx_small):
+    from openvo_amd.ransac import solve_pnp_ransac
+    X, uv, K4, R, t, out = _pnp_scene(800, 5, outlier_frac=0.2, noise=0.1)
+    K = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1.0]])
+    Rg, tg, mask, info = solve_pnp_ransac(X, uv, K, iters=300, threshold=1.5, context=ctx_small)
+    assert np.abs(Rg - R).max() < 3e-3 and np.abs(tg - t).max() < 3e-2 and info["best_count"] >= 0.7 * 800
+    with pytest.raises(Exception):
+        ctx_small.ransac_pnp(X[:3], uv[:3], K4, 10)

@@ -231,3 +231,42 @@ def test_bgr2gray_and_remap(oracle):
     out = oracle.remap_bilinear(src, m1, m2)
     assert out[0, 0] == (int(src[0, 0]) + int(src[0, 1]) + 1) // 2
     assert out[0, 7] == (int(src[0, 7]) * 16384 + (1 << 14)) >> 15           # x+1 outside: border 0
+
+
+def test_p3p_recovers_synthetic_poses(oracle):
+    """The PnP loop has no reference counterpart; its restatement is pinned by geometry instead: for
+    random poses and triangles the true pose is among the P3P candidates (float64, 1e-7)."""
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        r = rng.normal(size=3) * 0.3
+        th = np.linalg.norm(r)
+        k = r / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        t = rng.normal(size=3) * 0.5
+        X = rng.uniform(-2, 2, (3, 3)) + np.array([0, 0, 6.0])
+        Xc = X @ R.T + t
+        y = Xc / np.linalg.norm(Xc, axis=1, keepdims=True)
+        sols = oracle.p3p(y, X)
+        assert 1 <= len(sols) <= 4
+        assert min(np.abs(Rs - R).max() + np.abs(ts - t).max() for Rs, ts in sols) < 1e-7
+        for Rs, ts in sols:   # every candidate is a rotation that reproduces the three bearings
+            assert np.allclose(Rs @ Rs.T, np.eye(3), atol=1e-8) and np.linalg.det(Rs) > 0
+            Yc = X @ Rs.T + ts
+            assert np.allclose(Yc / np.linalg.norm(Yc, axis=1, keepdims=True), y, atol=1e-7)
+
+
+def test_ransac_pnp_oracle_finds_the_pose(oracle):
+    rng = np.random.default_rng(3)
+    n, f, cx, cy = 400, 700.0, 320.0, 240.0
+    X = np.stack([rng.uniform(-6, 6, n), rng.uniform(-3, 3, n), rng.uniform(4, 30, n)], 1)
+    R = np.eye(3)
+    t = np.array([0.1, 0.0, -0.25])
+    Xc = X @ R.T + t
+    uv = np.stack([f * Xc[:, 0] / Xc[:, 2] + cx, f * Xc[:, 1] / Xc[:, 2] + cy], 1)
+    out = rng.choice(n, 120, replace=False)
+    uv[out] += rng.uniform(-50, 50, (120, 2))
+    r = oracle.ransac_pnp(X, uv, [f, f, cx, cy], iters=200, thr=1.0, seed=7)
+    assert r["best_count"] >= 280 and r["counts"].max() == r["best_count"] and r["counts"][r["best_iter"]] == r["best_count"]
+    assert np.abs(r["Rt"][:, :3] - R).max() < 1e-3 and np.abs(r["Rt"][:, 3] - t).max() < 1e-2
+    assert r["mask"].sum() == r["best_count"]
