@@ -73,7 +73,9 @@ def main():
 
     K, W = args.steps, args.warmup
     c = Corridor(args.workload)
-    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h),
+    # config 4 is the 8-path (MODE_HH) cost-volume stress case; every other workload runs the reference's 5-path default
+    sgbm = c.sgbm_params(mode=1) if args.workload == "C4" else c.sgbm_params()
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), sgbm, (c.w, c.h),
                        device=(local_rank if (world == 1 or use_cuda) else local_rank % max(ndev, 1)),
                        max_keypoints=ODO_KW["nfeatures"])
     odo = StereoOdometer(cam, **ODO_KW)
@@ -172,8 +174,10 @@ def main():
             "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * dt_max / K, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "%s: stereo %dx%d corridor stream, SGBM D=%d 5-path (MODE_SGBM) + ORB %d + "
-                                   "Hamming kNN/ratio + 3-D lookup + rigid clique + Umeyama" % (args.workload, c.w, c.h, c.D, ODO_KW["nfeatures"]),
+            "config": {"workload": "%s: stereo %dx%d corridor stream, SGBM D=%d %s + ORB %d + "
+                                   "Hamming kNN/ratio + 3-D lookup + rigid clique + Umeyama"
+                                   % (args.workload, c.w, c.h, c.D, "8-path (MODE_HH)" if args.workload == "C4" else "5-path (MODE_SGBM)",
+                                      ODO_KW["nfeatures"]),
                        "odometer": {k: ODO_KW[k] for k in ("rigidity_threshold", "outlier_threshold", "match_threshold", "min_matches")},
                        "parallelism": "frame-sharded x%d, pose all_gather" % world,
                        "inputs": "host numpy every step (PCIe-inclusive)" if args.from_host else "resident in HBM"},
@@ -207,7 +211,7 @@ def cpu_baseline(c, cam, frames, W, n_pairs, odo_poses):
     n_pairs timed pairs of the same sequence, preceded by the halo frame so that every timed pair
     yields a pose.  Also returns the ATE between the GPU path and this CPU path on those pairs."""
     from oracle.odometer import RefStereoCamera, RefStereoOdometer
-    rcam = RefStereoCamera(cam.Q, cam.valid_region_left, c.sgbm_params())
+    rcam = RefStereoCamera(cam.Q, cam.valid_region_left, c.sgbm_params(mode=1) if c.name == "C4" else c.sgbm_params())
     kw = dict(ODO_KW)
     rodo = RefStereoOdometer(rcam, **kw)
     rodo.update(*frames[W - 1])               # untimed: establishes `current`

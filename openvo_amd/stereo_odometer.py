@@ -20,7 +20,15 @@ class StereoOdometer:
     MAX_ROTATION_CHANGE = np.pi / 3  # radians
 
     def __init__(self, stereo_camera, nfeatures=500, match_threshold=0.8, rigidity_threshold=0,
-                 outlier_threshold=0, preprocessed_frames=False, min_matches=10):
+                 outlier_threshold=0, preprocessed_frames=False, min_matches=10,
+                 pose_method="umeyama", pnp_iters=256, pnp_threshold=1.5, pnp_seed=4321):
+        """Arguments up to min_matches are the reference's [reference :14-15].  pose_method="pnp" is an
+        extension (not in openVO): the pair's pose comes from RANSAC solvePnP on the previous frame's 3-D
+        points and the new frame's keypoint pixels (vo_ransac_pnp) instead of the 3-D/3-D Umeyama fit;
+        the rigidity / outlier stages are then not used, the motion gates still apply."""
+        if pose_method not in ("umeyama", "pnp"):
+            raise ValueError("pose_method must be 'umeyama' or 'pnp'")
+        self.pose_method, self.pnp_iters, self.pnp_threshold, self.pnp_seed = pose_method, pnp_iters, pnp_threshold, pnp_seed
         self.stereo = stereo_camera
         self.current_img = self.current_disparity = self.current_3d = None
         self.prev_img = self.prev_disparity = self.prev_3d = None
@@ -133,6 +141,8 @@ class StereoOdometer:
               "_estimate", "_gate")
 
     def _try_pair(self, kps_a, desc_a, im3d_a, kps_b, desc_b, im3d_b):
+        if self.pose_method == "pnp":
+            return self._pair_pnp(kps_a, desc_a, im3d_a, kps_b, desc_b, im3d_b)
         # fused device path when nothing along the way was replaced by the user
         if (type(self) is StereoOdometer and type(self.matcher) is BFMatcher and 2 <= len(kps_b) and len(kps_a) <= 3800
                 and self._on_device(kps_a, desc_a, im3d_a) and self._on_device(kps_b, desc_b, im3d_b)
@@ -143,6 +153,30 @@ class StereoOdometer:
             self.skip_cause = "matches"
             return None
         return self.point_cloud_transform(pts_a, pts_b)
+
+    def _pair_pnp(self, kps_a, desc_a, im3d_a, kps_b, desc_b, im3d_b):
+        """Extension: pose of the pair by RANSAC solvePnP (3-D of frame a, pixels of frame b)."""
+        if not (self._on_device(kps_a, desc_a, im3d_a) and self._on_device(kps_b, desc_b, im3d_b) and len(kps_b) >= 2):
+            raise ValueError("pose_method='pnp' needs the device-resident frames compute_3d returns")
+        q, t, pts_a, _, st_a, _ = self._ctx.point_clouds(kps_a.frame.slot, kps_b.frame.slot, self.match_threshold)
+        if len(q) < self.min_matches:
+            self.skip_cause = "matches"
+            return None
+        if (st_a == 2).any():
+            raise ZeroDivisionError("division by zero")
+        ok = (st_a == 0) & np.isfinite(pts_a).all(axis=1)
+        x0, y0 = kps_b.frame.roi[0], kps_b.frame.roi[1]
+        uv = kps_b.xy[t[ok]] + np.array([x0, y0], np.float32)      # keypoints live in the cropped image
+        Q = self.stereo.Q
+        K4 = [Q[2, 3], Q[2, 3], -Q[0, 3], -Q[1, 3]]
+        if ok.sum() < max(self.min_matches, 4):
+            self.skip_cause = "matches"
+            return None
+        r = self._ctx.ransac_pnp(pts_a[ok], uv, K4, self.pnp_iters, self.pnp_threshold, self.pnp_seed)
+        if r["best_count"] < self.min_matches:
+            self.skip_cause = "outlier"
+            return None
+        return self._gate(np.vstack([r["Rt"], [0, 0, 0, 1]]))
 
     def _pair_fused(self, slot_a, slot_b):
         """point_clouds + point_cloud_transform in one native call (one device synchronisation);

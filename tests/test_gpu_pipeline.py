@@ -258,3 +258,21 @@ def test_submitted_host_pairs_equal_plain_updates(depth):
     cam.compute_3d(h, None)
     with pytest.raises(ValueError):
         cam.compute_3d(h, None)
+
+
+def test_pnp_pose_mode_tracks_the_corridor():
+    """Extension (no reference counterpart): pose_method="pnp" runs the RANSAC solvePnP loop on the
+    previous frame's 3-D points and the new keypoints; on the synthetic corridor it must follow the
+    analytic ground truth about as well as the reference's 3-D/3-D fit does."""
+    c, cam = _rig("C1", max_keypoints=500)
+    frames = c.pairs(0, 12)
+    pnp = StereoOdometer(cam, preprocessed_frames=True, pose_method="pnp")
+    ume = StereoOdometer(cam, preprocessed_frames=True, rigidity_threshold=0.1, outlier_threshold=0.02)
+    for L, R in frames:
+        assert pnp.update(L, R) and ume.update(L, R)
+    gt = np.linalg.inv(Corridor.gt_pose(0)) @ Corridor.gt_pose(11)
+    e_pnp = np.linalg.norm(pnp.current_pose()[:3, 3] - gt[:3, 3])
+    e_ume = np.linalg.norm(ume.current_pose()[:3, 3] - gt[:3, 3])
+    assert e_pnp < 0.05 and e_pnp < 3 * e_ume + 0.02
+    with pytest.raises(ValueError):
+        StereoOdometer(cam, pose_method="icp")
