@@ -276,3 +276,27 @@ def test_pnp_pose_mode_tracks_the_corridor():
     assert e_pnp < 0.05 and e_pnp < 3 * e_ume + 0.02
     with pytest.raises(ValueError):
         StereoOdometer(cam, pose_method="icp")
+
+
+def test_lookahead_keypoints_are_recomputed_when_the_request_differs():
+    """Keypoints extracted ahead of time on a look-ahead engine are only handed out for the very
+    arguments they were computed with; any other request recomputes and gives what a context without
+    look-ahead gives."""
+    c, cam = _rig("C1", max_keypoints=500)
+    frames = c.pairs(0, 8)
+    staged = cam.stage_pairs(frames)
+    a = StereoOdometer(cam, nfeatures=500, preprocessed_frames=True)
+    for i in range(4):
+        assert a.update(staged[i], None)            # frames 4.. are now in flight with 500-feature keypoints
+    b = StereoOdometer(cam, nfeatures=300, preprocessed_frames=True)
+    x3, disp, left = cam.compute_3d(staged[4], None, preprocessed=True)
+    kps300, desc300 = b.orb.detectAndCompute(left, b.feature_mask(disp))
+    kps500, desc500 = a.orb.detectAndCompute(left, a.feature_mask(disp))
+    c2, cam2 = _rig("C1", max_keypoints=500)
+    cam2.lookahead = 0
+    x3b, dispb, leftb = cam2.compute_3d(frames[4][0], frames[4][1], preprocessed=True)
+    for nf, (k, d) in ((300, (kps300, desc300)), (500, (kps500, desc500))):
+        o = StereoOdometer(cam2, nfeatures=nf, preprocessed_frames=True)
+        kr, dr = o.orb.detectAndCompute(leftb, o.feature_mask(dispb))
+        assert len(k) == len(kr) and np.array_equal(k.xy, kr.xy) and np.array_equal(d, dr)
+    assert len(kps300) < len(kps500)
