@@ -309,6 +309,40 @@ __device__ __forceinline__ void lv_store(int16_t* p, const LV<NP>& v)
         for (int k = 0; k < NP; k++) ((uint32_t*)p)[k] = v.r[k];
     }
 }
+// Non-temporal variants for the streams that are touched exactly once more (every L volume: written by
+// k_sgbm_paths, read by the fused sweep) or never again (C in the fused sweep): they should not displace
+// the cost volume, which is re-read by every direction, from L2 / the Infinity Cache.  +6 % pairs/s.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int NP>
+__device__ __forceinline__ void lv_store_nt(int16_t* p, const LV<NP>& v)
+{
+    if constexpr (NP % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < NP / 4; k++) {
+            u32x4 t = { v.r[4 * k], v.r[4 * k + 1], v.r[4 * k + 2], v.r[4 * k + 3] };
+            __builtin_nontemporal_store(t, (u32x4*)p + k);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; k++) __builtin_nontemporal_store(v.r[k], (uint32_t*)p + k);
+    }
+}
+template <int NP>
+__device__ __forceinline__ LV<NP> lv_load_nt(const int16_t* p)
+{
+    LV<NP> v;
+    if constexpr (NP % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < NP / 4; k++) {
+            u32x4 t = __builtin_nontemporal_load((const u32x4*)p + k);
+            v.r[4 * k] = t.x; v.r[4 * k + 1] = t.y; v.r[4 * k + 2] = t.z; v.r[4 * k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; k++) v.r[k] = __builtin_nontemporal_load((const uint32_t*)p + k);
+    }
+    return v;
+}
 template <int NP>
 __device__ __forceinline__ LV<NP> lv_fill(uint32_t x)
 {
@@ -424,7 +458,7 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
             const uint32_t mn = row_min_u32(lane_min16<NP>(L));
             delta2 = pk_add(pk_rep((int)mn), P2_2);
             Lp = L;
-            lv_store<NP>(i < n ? pst : sink, L);
+            lv_store_nt<NP>(i < n ? pst : sink, L);
             pst += stride;
         }
     }
@@ -631,9 +665,9 @@ __global__ void __launch_bounds__(256) k_sgbm_vwta(const int16_t* __restrict__ C
 #pragma unroll
     for (int k = 0; k < PF; k++) {
         if (k < g.H) {
-            cbuf[k] = lv_load<NP>(rowC + start);
+            cbuf[k] = lv_load_nt<NP>(rowC + start);
 #pragma unroll
-            for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load<NP>(rowL + (size_t)v * vol + start);
+            for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
             rowC += stride;
             rowL += stride;
         }
@@ -650,9 +684,9 @@ __global__ void __launch_bounds__(256) k_sgbm_vwta(const int16_t* __restrict__ C
 #pragma unroll
                     for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], lbuf[k][v].r[q]);
                 if (y + PF < g.H) {
-                    cbuf[k] = lv_load<NP>(rowC + start);
+                    cbuf[k] = lv_load_nt<NP>(rowC + start);
 #pragma unroll
-                    for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load<NP>(rowL + (size_t)v * vol + start);
+                    for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
                     rowC += stride;
                     rowL += stride;
                 }
