@@ -117,6 +117,10 @@ int vo_orb_detect_and_compute_host(vo_ctx* ctx, const uint8_t* img, int w, int h
                                    float* kp_response, int32_t* kp_octave, uint8_t* desc, int cap,
                                    int* n_out);
 int vo_slot_num_keypoints(vo_ctx* ctx, int slot, int* n_out);
+/* download what vo_orb_detect_and_compute left in the slot (when that call passed NULL outputs to keep
+ * everything on the device); any output may be NULL */
+int vo_download_keypoints(vo_ctx* ctx, int slot, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
+                          int32_t* kp_octave, uint8_t* desc, int cap, int* n_out);
 
 /* matching (stereo_odometer.py:163-164) ------------------------------------------------ */
 /* matcher.knnMatch(q, t, k=2) with NORM_HAMMING: idx/dist nq*2, ascending distance, ties ->

@@ -24,7 +24,7 @@ SYMBOLS = [
     "vo_set_lookahead_orb", "vo_prefetch_pair",
     "vo_sgbm_compute", "vo_sgbm_compute_host", "vo_download_disparity_f32", "vo_download_xyz",
     "vo_download_left", "vo_download_right", "vo_cvt_bgr2gray", "vo_remap", "vo_reproject_to_3d",
-    "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints",
+    "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints", "vo_download_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_ransac_essential", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
     "vo_sgbm_last_geometry",
@@ -91,6 +91,7 @@ def lib():
         L.vo_orb_detect_and_compute.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]
         L.vo_orb_detect_and_compute_host.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]
         L.vo_slot_num_keypoints.argtypes = [vp, ci, vp]
+        L.vo_download_keypoints.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, vp]
         L.vo_bf_knn2_hamming.argtypes = [vp, vp, ci, vp, ci, vp, vp]
         L.vo_ratio_filter.argtypes = [vp, vp, ci, cd, vp, vp, vp]
         L.vo_points3d_at.argtypes = [vp, ci, vp, ci, vp, vp]
@@ -285,6 +286,21 @@ class Context:
                                                      int(max_d16), _p(b["xy"]), _p(b["size"]), _p(b["angle"]),
                                                      _p(b["response"]), _p(b["octave"]), _p(b["desc"]), cap,
                                                      ctypes.byref(n)))
+        return self._trim(b, n.value)
+
+    def orb_slot_count(self, slot, nfeatures, mask_mode, min_d16=0, max_d16=0):
+        """Same extraction, everything stays on the device: returns only the keypoint count."""
+        n = ctypes.c_int(0)
+        self._ck(self._lib.vo_orb_detect_and_compute(self._h, slot, int(nfeatures), int(mask_mode), int(min_d16),
+                                                     int(max_d16), None, None, None, None, None, None, 0, ctypes.byref(n)))
+        return n.value
+
+    def download_keypoints(self, slot):
+        cap = self.kp_cap
+        b = self._kp_buffers(cap)
+        n = ctypes.c_int(0)
+        self._ck(self._lib.vo_download_keypoints(self._h, slot, _p(b["xy"]), _p(b["size"]), _p(b["angle"]), _p(b["response"]),
+                                                 _p(b["octave"]), _p(b["desc"]), cap, ctypes.byref(n)))
         return self._trim(b, n.value)
 
     def orb_host(self, img, mask, nfeatures):

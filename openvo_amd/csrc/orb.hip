@@ -730,6 +730,18 @@ extern "C" int vo_orb_detect_and_compute(vo_ctx* ctx, int slot, int nfeatures, i
     return download_kps(ctx, f, kp_xy, kp_size, kp_angle, kp_response, kp_octave, desc, cap, n_out);
 }
 
+// keypoints + descriptors a slot already holds (no recomputation); any output may be NULL
+extern "C" int vo_download_keypoints(vo_ctx* ctx, int slot, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
+                                     int32_t* kp_octave, uint8_t* desc, int cap, int* n_out)
+{
+    if (!ctx || slot < 0 || slot >= VO_NUM_SLOTS) return vo_fail(ctx, VO_E_ARG, "vo_download_keypoints: bad slot");
+    FrameSlot& f = ctx->slots[slot];
+    if (!f.has_kp) return vo_fail(ctx, VO_E_STATE, "slot %d holds no keypoints", slot);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    { int rcw = slot_wait(ctx, f); if (rcw) return rcw; }
+    return download_kps(ctx, f, kp_xy, kp_size, kp_angle, kp_response, kp_octave, desc, cap, n_out);
+}
+
 extern "C" int vo_orb_detect_and_compute_host(vo_ctx* ctx, const uint8_t* img, int w, int h, int stride, const uint8_t* mask,
                                               int mask_stride, int nfeatures, float* kp_xy, float* kp_size, float* kp_angle,
                                               float* kp_response, int32_t* kp_octave, uint8_t* desc, int cap, int* n_out)

@@ -36,17 +36,33 @@ class DMatch:
 
 
 class KeyPointList:
-    """Sequence of KeyPoint backed by arrays (no per-keypoint Python objects until indexed)."""
+    """Sequence of KeyPoint backed by arrays (no per-keypoint Python objects until indexed).  A list that
+    came out of the fused device path holds only its length until an array is asked for: the odometer's
+    own matching / pose steps read keypoints and descriptors in the frame's device slot."""
 
-    def __init__(self, arrays, frame=None):
-        self.xy = arrays["xy"]
-        self.size, self.angle = arrays["size"], arrays["angle"]
-        self.response, self.octave = arrays["response"], arrays["octave"]
+    _FIELDS = ("xy", "size", "angle", "response", "octave")
+
+    def __init__(self, arrays=None, frame=None, n=None):
+        self._arr = arrays
+        self._n = len(arrays["xy"]) if arrays is not None else int(n)
         self.frame = frame          # FrameHandle whose slot holds these keypoints on the device
         self.desc = None            # the descriptor array returned together with this list
 
+    def _load(self):
+        if self._arr is None:
+            if self.frame is None or not self.frame.live:
+                raise RuntimeError("keypoints were not materialised before their frame left the device")
+            self._arr = self.frame.ctx.download_keypoints(self.frame.slot)
+        return self._arr
+
+    xy = property(lambda self: self._load()["xy"])
+    size = property(lambda self: self._load()["size"])
+    angle = property(lambda self: self._load()["angle"])
+    response = property(lambda self: self._load()["response"])
+    octave = property(lambda self: self._load()["octave"])
+
     def __len__(self):
-        return len(self.xy)
+        return self._n
 
     def __getitem__(self, i):
         if isinstance(i, slice):
@@ -55,10 +71,47 @@ class KeyPointList:
             i += len(self)
         if not 0 <= i < len(self):
             raise IndexError("keypoint index out of range")
-        return KeyPoint(self.xy[i, 0], self.xy[i, 1], self.size[i], self.angle[i], self.response[i], self.octave[i])
+        a = self._load()
+        return KeyPoint(a["xy"][i, 0], a["xy"][i, 1], a["size"][i], a["angle"][i], a["response"][i], a["octave"][i])
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
+
+
+class DeviceDescriptors:
+    """The (N, 32) uint8 descriptor array of a device-resident KeyPointList; np.asarray() downloads it.
+    (Holds its list weakly: frame -> nothing, list -> descriptors -> frame, so no reference cycle keeps
+    a frame slot alive after the odometer has dropped the frame.)"""
+
+    dtype = np.dtype(np.uint8)
+    ndim = 2
+
+    def __init__(self, kps):
+        import weakref
+        self.frame, self._n, self._kref, self._arr = kps.frame, len(kps), weakref.ref(kps), None
+
+    shape = property(lambda self: (self._n, 32))
+
+    def __len__(self):
+        return self._n
+
+    def _load(self):
+        if self._arr is None:
+            k = self._kref()
+            if k is not None:
+                self._arr = k._load()["desc"]
+            elif self.frame is not None and self.frame.live:
+                self._arr = self.frame.ctx.download_keypoints(self.frame.slot)["desc"]
+            else:
+                raise RuntimeError("descriptors were not materialised before their frame left the device")
+        return self._arr
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._load()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, i):
+        return self._load()[i]
 
 
 class FrameHandle:
@@ -69,6 +122,7 @@ class FrameHandle:
         self.w, self.h = w, h
         self.roi = roi                      # (x0, y0, x1, y1) numpy-slice bounds, already clipped
         self._cache = {}
+        self._lazy_kps = []                 # weak refs of KeyPointLists still living only in the slot
 
     @property
     def live(self):
@@ -90,9 +144,18 @@ class FrameHandle:
                 self._cache[kind] = self.ctx.download_left(self.slot, (self.h, self.w))
         return self._cache[kind]
 
+    def materialize_keypoints(self):
+        """Download keypoint lists that exist only in the slot (before the slot's keypoints change)."""
+        for ref in self._lazy_kps:
+            k = ref()
+            if k is not None:
+                k._load()
+        self._lazy_kps = []
+
     def evict(self):
         """Detach from the device slot, keeping host copies of everything."""
         if self.live:
+            self.materialize_keypoints()
             for kind in ("disp", "xyz", "left"):
                 self.full(kind)
             self.slot = None
@@ -177,9 +240,10 @@ class ORB:
                 (mask is None or (isinstance(mask, DisparityMask) and mask.frame is image.frame))):
             # fused path: image, disparity-range mask, keypoints and descriptors never leave the GPU
             frame = image.frame
+            frame.materialize_keypoints()     # an earlier list of this frame must not see the new extraction
             if mask is None:
                 self._ctx.lookahead_orb(self.nfeatures, 0, 0, 0)
-                arr = self._ctx.orb_slot(frame.slot, self.nfeatures, 0)
+                n = self._ctx.orb_slot_count(frame.slot, self.nfeatures, 0)
             else:
                 # d >= lo and d <= hi on d = disp16/16 (exact in float32) <=> integer compare
                 # (the reference compares float32 arrays with Python numbers: thresholds round to float32)
@@ -187,12 +251,18 @@ class ORB:
                 hi16 = int(np.floor(float(np.float32(mask.hi)) * 16.0))
                 # frames prefetched from here on get their keypoints extracted right behind their SGBM
                 self._ctx.lookahead_orb(self.nfeatures, 1, lo16, hi16)
-                arr = self._ctx.orb_slot(frame.slot, self.nfeatures, 1, lo16, hi16)
-        else:
-            img = np.asarray(image)
-            if img.ndim == 3:
-                img = self._ctx.cvt_bgr2gray(img)
-            arr = self._ctx.orb_host(img, None if mask is None else np.asarray(mask), self.nfeatures)
+                n = self._ctx.orb_slot_count(frame.slot, self.nfeatures, 1, lo16, hi16)
+            if n == 0:
+                return (), None
+            import weakref
+            kps = KeyPointList(None, frame, n)
+            kps.desc = DeviceDescriptors(kps)
+            frame._lazy_kps += [weakref.ref(kps), weakref.ref(kps.desc)]
+            return kps, kps.desc
+        img = np.asarray(image)
+        if img.ndim == 3:
+            img = self._ctx.cvt_bgr2gray(img)
+        arr = self._ctx.orb_host(img, None if mask is None else np.asarray(mask), self.nfeatures)
         kps = KeyPointList(arr, frame)
         if len(kps) == 0:
             return (), None               # cv2 returns an empty tuple and None
