@@ -157,6 +157,13 @@ int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int32_t* 
  * NULL.  The caller applies the motion gates [:207-221]. */
 int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int min_matches, double rigidity_thr,
                  double outlier_thr, int32_t* counts4, int32_t* rc2, double* T1_12, double* T2_12);
+/* the same step split in two so that the host does not wait for it: _begin enqueues it on a stream of its
+ * own (ordered behind the producers of both slots) and returns a ticket, _end waits for that ticket and
+ * delivers what vo_pose_pair would have.  At most three tickets may be open.  Lets the pose of pair (i, i+1)
+ * run while the caller still handles pair (i-1, i). */
+int vo_pose_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int min_matches, double rigidity_thr,
+                       double outlier_thr, int* ticket_out);
+int vo_pose_pair_end(vo_ctx* ctx, int ticket, int32_t* counts4, int32_t* rc2, double* T1_12, double* T2_12);
 
 /* pose (stereo_odometer.py:82-105,177-223) ---------------------------------------------- */
 /* cv2.estimateAffine3D(src, dst, force_rotation) Umeyama [:190,204]: T 3x4 row-major, scale */

@@ -7,10 +7,11 @@ libvo355.so (hand-written HIP for gfx950, C ABI in include/vo355.h); there is no
 """
 import os as _os
 
-# The look-ahead engines run on their own HIP streams; the runtime multiplexes streams onto 4 hardware
-# queues by default, which would serialise engines that happen to share one.  Must be set before the
+# The look-ahead engines (6) and the ahead-of-time pose steps (3) run on their own HIP streams next to the
+# main one; the runtime multiplexes streams onto 4 hardware queues by default, which would serialise
+# whichever of them happen to share one.  Must be set before the
 # HIP runtime initialises (a process that has already created a HIP context keeps its own setting).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "10")
 
 from .stereo_camera import StereoCamera
 from .stereo_odometer import StereoOdometer

@@ -26,7 +26,7 @@ SYMBOLS = [
     "vo_download_left", "vo_download_right", "vo_cvt_bgr2gray", "vo_remap", "vo_reproject_to_3d",
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints", "vo_download_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
-    "vo_pose_pair", "vo_ransac_essential", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
+    "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
     "vo_sgbm_last_geometry",
 ]
 
@@ -98,6 +98,8 @@ def lib():
         L.vo_bilinear_at.argtypes = [vp, vp, ci, ci, vp, ci, vp, vp]
         L.vo_point_clouds.argtypes = [vp, ci, ci, cd, vp, vp, vp, vp, vp, vp, ci, vp]
         L.vo_pose_pair.argtypes = [vp, ci, ci, cd, ci, cd, cd, vp, vp, vp, vp]
+        L.vo_pose_pair_begin.argtypes = [vp, ci, ci, cd, ci, cd, cd, vp]
+        L.vo_pose_pair_end.argtypes = [vp, ci, vp, vp, vp, vp]
         L.vo_ransac_essential.argtypes = [vp, vp, vp, ci, vp, ci, ctypes.c_float, ctypes.c_uint32, vp, vp, vp, vp]
         L.vo_ransac_pnp.argtypes = [vp, vp, vp, ci, vp, ci, ctypes.c_float, ctypes.c_uint32, vp, vp, vp, vp]
         L.vo_umeyama.argtypes = [vp, vp, vp, ci, ci, vp, vp]
@@ -379,6 +381,20 @@ class Context:
         T2 = np.full((3, 4), np.nan)
         self._ck(self._lib.vo_pose_pair(self._h, int(slot_a), int(slot_b), float(ratio), int(min_matches),
                                         float(rigidity_thr), float(outlier_thr), _p(counts), _p(rc), _p(T1), _p(T2)))
+        return counts, rc, T1, T2
+
+    def pose_pair_begin(self, slot_a, slot_b, ratio, min_matches, rigidity_thr, outlier_thr):
+        t = ctypes.c_int(-1)
+        self._ck(self._lib.vo_pose_pair_begin(self._h, int(slot_a), int(slot_b), float(ratio), int(min_matches),
+                                              float(rigidity_thr), float(outlier_thr), ctypes.byref(t)))
+        return t.value
+
+    def pose_pair_end(self, ticket):
+        counts = np.zeros(4, np.int32)
+        rc = np.ones(2, np.int32)
+        T1 = np.full((3, 4), np.nan)
+        T2 = np.full((3, 4), np.nan)
+        self._ck(self._lib.vo_pose_pair_end(self._h, int(ticket), _p(counts), _p(rc), _p(T1), _p(T2)))
         return counts, rc, T1, T2
 
     def ransac_essential(self, pts1, pts2, K4, iters=5000, thr=1.0, seed=4321, want_counts=False):

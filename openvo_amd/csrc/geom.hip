@@ -1062,29 +1062,17 @@ __global__ void k_pose_init(PoseOut* out, const int* __restrict__ m_dev, int* __
 }
 __global__ void k_pose_flags(PoseOut* out, const int* __restrict__ flags_dev) { out->flags |= *flags_dev; }
 
-extern "C" int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int min_matches, double rigidity_thr,
-                            double outlier_thr, int32_t* counts4 /*M,n1,n2,flags*/, int32_t* rc2 /*first,final*/,
-                            double* T1_12, double* T2_12)
+// enqueue the whole fused step for two slots on ctx->stream with the scratch currently installed in ctx; the
+// PoseOut record is copied to host_out (pinned) at the end.  No host synchronisation.
+static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, int min_matches, double rigidity_thr,
+                        double outlier_thr, void* host_out)
 {
-    if (!ctx || slot_a < 0 || slot_a >= VO_NUM_SLOTS || slot_b < 0 || slot_b >= VO_NUM_SLOTS || !counts4 || !rc2 || !T2_12)
-        return vo_fail(ctx, VO_E_ARG, "vo_pose_pair: bad argument");
-    FrameSlot& a = ctx->slots[slot_a];
-    FrameSlot& b = ctx->slots[slot_b];
-    if (!a.has_kp || !b.has_kp || !a.has_disp || !b.has_disp) return vo_fail(ctx, VO_E_STATE, "slots need disparity and keypoints");
-    { int rcw = slot_wait(ctx, a); if (!rcw) rcw = slot_wait(ctx, b); if (rcw) return rcw; }
-    if (!ctx->has_Q) return vo_fail(ctx, VO_E_STATE, "vo_set_Q has not been called");
-    counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
-    rc2[0] = rc2[1] = 1;
-    if (a.n_kp == 0) return VO_OK;
-    if (b.n_kp < 2) return vo_fail(ctx, VO_E_ARG, "train set has fewer than 2 descriptors (reference raises IndexError)");
     const int nq = a.n_kp;
-    if (nq >= 32768 || (size_t)nq * 16 > 60 * 1024) return vo_fail(ctx, VO_E_CAP, "%d query keypoints exceed the fused pose path", nq);
-    VO_HIP(ctx, hipSetDevice(ctx->device));
     // workspace: bit matrix + ncons + filtered point sets + residuals + result
     const int words = (nq + 63) / 64;
     const size_t need = (size_t)nq * words * 8 + (size_t)nq * 4 + (size_t)nq * 12 * 4 + (size_t)nq * 8 + 4096;
     if (ctx->clique_ws_bytes < need) {
-        if (ctx->clique_ws) (void)hipFree(ctx->clique_ws);
+        if (ctx->clique_ws) { VO_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->clique_ws); }
         ctx->clique_ws = nullptr; ctx->clique_ws_bytes = 0;
         VO_HIP(ctx, hipMalloc((void**)&ctx->clique_ws, need));
         ctx->clique_ws_bytes = need;
@@ -1133,13 +1121,139 @@ extern "C" int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, i
         hipLaunchKernelGGL(k_pose_flags, dim3(1), dim3(1), 0, ctx->stream, d_out, d_flags);
         hipLaunchKernelGGL(k_pose_fit, dim3(1), dim3(1024), 0, ctx->stream, d_qa, d_qb, outlier_thr, min_matches, d_errs, d_ra, d_rb, d_out);
         VO_CHECK_LAUNCH(ctx);
-        VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_out, sizeof(PoseOut), hipMemcpyDeviceToHost, ctx->stream));
-        if ((rc = xfer_flush(ctx))) return rc;
+        VO_HIP(ctx, hipMemcpyAsync(host_out, d_out, sizeof(PoseOut), hipMemcpyDeviceToHost, ctx->stream));
     }
-    const PoseOut* o = (const PoseOut*)ctx->pinned;
+    return VO_OK;
+}
+
+static int pose_check(vo_ctx* ctx, int slot_a, int slot_b)
+{
+    if (!ctx || slot_a < 0 || slot_a >= VO_NUM_SLOTS || slot_b < 0 || slot_b >= VO_NUM_SLOTS) return vo_fail(ctx, VO_E_ARG, "vo_pose_pair: bad argument");
+    FrameSlot& a = ctx->slots[slot_a];
+    FrameSlot& b = ctx->slots[slot_b];
+    if (!a.has_kp || !b.has_kp || !a.has_disp || !b.has_disp) return vo_fail(ctx, VO_E_STATE, "slots need disparity and keypoints");
+    if (!ctx->has_Q) return vo_fail(ctx, VO_E_STATE, "vo_set_Q has not been called");
+    if (a.n_kp > 0 && b.n_kp < 2) return vo_fail(ctx, VO_E_ARG, "train set has fewer than 2 descriptors (reference raises IndexError)");
+    if (a.n_kp >= 32768 || (size_t)a.n_kp * 16 > 60 * 1024) return vo_fail(ctx, VO_E_CAP, "%d query keypoints exceed the fused pose path", a.n_kp);
+    return VO_OK;
+}
+
+static void pose_unpack(const void* rec, int32_t* counts4, int32_t* rc2, double* T1_12, double* T2_12)
+{
+    const PoseOut* o = (const PoseOut*)rec;
     counts4[0] = o->M; counts4[1] = o->n1; counts4[2] = o->n2; counts4[3] = o->flags;
     rc2[0] = o->rc1; rc2[1] = o->rc2;
     if (T1_12) memcpy(T1_12, o->T1, sizeof(o->T1));
     memcpy(T2_12, o->T2, sizeof(o->T2));
+}
+
+extern "C" int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int min_matches, double rigidity_thr,
+                            double outlier_thr, int32_t* counts4 /*M,n1,n2,flags*/, int32_t* rc2 /*first,final*/,
+                            double* T1_12, double* T2_12)
+{
+    if (!counts4 || !rc2 || !T2_12) return vo_fail(ctx, VO_E_ARG, "vo_pose_pair: bad argument");
+    int rc = pose_check(ctx, slot_a, slot_b);
+    if (rc) return rc;
+    FrameSlot& a = ctx->slots[slot_a];
+    FrameSlot& b = ctx->slots[slot_b];
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    { int rcw = slot_wait(ctx, a); if (!rcw) rcw = slot_wait(ctx, b); if (rcw) return rcw; }
+    counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
+    rc2[0] = rc2[1] = 1;
+    if (a.n_kp == 0) return VO_OK;
+    if ((rc = pose_enqueue(ctx, a, b, ratio, min_matches, rigidity_thr, outlier_thr, ctx->pinned))) return rc;
+    if ((rc = xfer_flush(ctx))) return rc;
+    pose_unpack(ctx->pinned, counts4, rc2, T1_12, T2_12);
+    return VO_OK;
+}
+
+// swap the match / pose scratch and the stream with alternate k; calling it twice restores the context
+static void pose_swap(vo_ctx* ctx, int k)
+{
+    vo_ctx::PoseAlt& p = ctx->pose_alt[k];
+    std::swap(ctx->stream, p.stream);
+    std::swap(ctx->m_idx, p.m_idx); std::swap(ctx->m_count, p.m_count); std::swap(ctx->m_dist, p.m_dist);
+    std::swap(ctx->mq_idx, p.mq_idx); std::swap(ctx->mt_idx, p.mt_idx);
+    std::swap(ctx->pts_a, p.pts_a); std::swap(ctx->pts_b, p.pts_b); std::swap(ctx->xy_a, p.xy_a); std::swap(ctx->xy_b, p.xy_b);
+    std::swap(ctx->st_a, p.st_a); std::swap(ctx->st_b, p.st_b);
+    std::swap(ctx->clique_ws, p.clique_ws); std::swap(ctx->clique_ws_bytes, p.clique_ws_bytes);
+}
+
+static int pose_alt_prepare(vo_ctx* ctx, int k)
+{
+    vo_ctx::PoseAlt& p = ctx->pose_alt[k];
+    if (p.ready) return VO_OK;
+    const size_t cap = (size_t)ctx->kp_cap;
+    VO_HIP(ctx, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    VO_HIP(ctx, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+    VO_HIP(ctx, hipHostMalloc(&p.result, 1024, hipHostMallocDefault));
+    VO_HIP(ctx, hipMalloc((void**)&p.m_idx, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.m_dist, cap * 8 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.m_count, 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.mq_idx, cap * 4 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.mt_idx, cap * 4 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.pts_a, cap * 12 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.pts_b, cap * 12 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.xy_a, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.xy_b, cap * 8 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.st_a, cap + 256)); VO_HIP(ctx, hipMalloc((void**)&p.st_b, cap + 256));
+    p.ready = true;
+    return VO_OK;
+}
+
+void pose_alt_free(vo_ctx* ctx)
+{
+    for (int k = 0; k < vo_ctx::N_POSE_ALT; k++) {
+        vo_ctx::PoseAlt& p = ctx->pose_alt[k];
+        if (p.stream) (void)hipStreamSynchronize(p.stream);
+        void* ps[] = { p.m_idx, p.m_dist, p.m_count, p.mq_idx, p.mt_idx, p.pts_a, p.pts_b, p.xy_a, p.xy_b, p.st_a, p.st_b, p.clique_ws };
+        for (void* q : ps) if (q) (void)hipFree(q);
+        if (p.result) (void)hipHostFree(p.result);
+        if (p.done) (void)hipEventDestroy(p.done);
+        if (p.stream) (void)hipStreamDestroy(p.stream);
+        p = vo_ctx::PoseAlt();
+    }
+}
+
+extern "C" int vo_pose_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int min_matches, double rigidity_thr,
+                                  double outlier_thr, int* ticket_out)
+{
+    if (!ticket_out) return vo_fail(ctx, VO_E_ARG, "vo_pose_pair_begin: bad argument");
+    int rc = pose_check(ctx, slot_a, slot_b);
+    if (rc) return rc;
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    const int k = ctx->pose_next;
+    vo_ctx::PoseAlt& p = ctx->pose_alt[k];
+    if (p.busy) return vo_fail(ctx, VO_E_STATE, "vo_pose_pair_begin: every asynchronous pose step is still open (end one first)");
+    if ((rc = pose_alt_prepare(ctx, k))) return rc;
+    FrameSlot& a = ctx->slots[slot_a];
+    FrameSlot& b = ctx->slots[slot_b];
+    PoseOut* rec = (PoseOut*)p.result;
+    memset(rec, 0, sizeof(PoseOut));
+    rec->rc1 = rec->rc2 = 1;
+    // the step runs on the alternate's own stream: order it behind whatever still produces the two slots
+    // (look-ahead engines) and behind the main stream's work on them
+    VO_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    pose_swap(ctx, k);
+    hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev0, 0);
+    if (e == hipSuccess && a.pending) e = hipStreamWaitEvent(ctx->stream, a.ready, 0);
+    if (e == hipSuccess && b.pending) e = hipStreamWaitEvent(ctx->stream, b.ready, 0);
+    rc = e == hipSuccess ? VO_OK : vo_fail(ctx, VO_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+    if (!rc && a.n_kp > 0) rc = pose_enqueue(ctx, a, b, ratio, min_matches, rigidity_thr, outlier_thr, rec);
+    if (!rc && hipEventRecord(p.done, ctx->stream) != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
+    pose_swap(ctx, k);
+    if (rc) return rc;
+    p.busy = true; p.slot_a = slot_a; p.slot_b = slot_b;
+    p.params[0] = ratio; p.params[1] = min_matches; p.params[2] = rigidity_thr; p.params[3] = outlier_thr;
+    ctx->pose_next = (k + 1) % vo_ctx::N_POSE_ALT;
+    *ticket_out = k;
+    return VO_OK;
+}
+
+extern "C" int vo_pose_pair_end(vo_ctx* ctx, int ticket, int32_t* counts4, int32_t* rc2, double* T1_12, double* T2_12)
+{
+    if (!ctx || ticket < 0 || ticket >= vo_ctx::N_POSE_ALT || !counts4 || !rc2 || !T2_12) return vo_fail(ctx, VO_E_ARG, "vo_pose_pair_end: bad argument");
+    vo_ctx::PoseAlt& p = ctx->pose_alt[ticket];
+    if (!p.busy) return vo_fail(ctx, VO_E_STATE, "vo_pose_pair_end: ticket %d is not open", ticket);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    p.busy = false;
+    VO_HIP(ctx, hipEventSynchronize(p.done));
+    pose_unpack(p.result, counts4, rc2, T1_12, T2_12);
     return VO_OK;
 }

@@ -714,9 +714,15 @@ extern "C" int vo_orb_detect_and_compute(vo_ctx* ctx, int slot, int nfeatures, i
     if (mask_mode == 1 && !f.has_disp) return vo_fail(ctx, VO_E_STATE, "slot %d holds no disparity for the fused mask", slot);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     const int params[4] = { nfeatures, mask_mode, min_disp16, max_disp16 };
-    const bool prefetched = f.kp_pending && !memcmp(params, f.kp_params, sizeof(params));
+    const bool same = !memcmp(params, f.kp_params, sizeof(params));
+    const bool prefetched = f.kp_pending && same;
     f.kp_pending = false;
     int rc;
+    if (f.has_kp && same) {
+        // the slot already holds exactly this extraction (an earlier call, e.g. ahead of a pose step)
+        if ((rc = slot_wait(ctx, f))) return rc;
+        return download_kps(ctx, f, kp_xy, kp_size, kp_angle, kp_response, kp_octave, desc, cap, n_out);
+    }
     if (prefetched) {
         // the look-ahead engine extracted these keypoints behind the SGBM: wait for it, nothing to launch
         VO_HIP(ctx, hipEventSynchronize(f.ready));
@@ -725,6 +731,7 @@ extern "C" int vo_orb_detect_and_compute(vo_ctx* ctx, int slot, int nfeatures, i
         if ((rc = slot_wait(ctx, f))) return rc;
         if ((rc = orb_slot_enqueue(ctx, f, nfeatures, mask_mode, min_disp16, max_disp16))) return rc;
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(f.kp_params, params, sizeof(params));
     }
     if ((rc = orb_finish(ctx, &f))) return rc;
     return download_kps(ctx, f, kp_xy, kp_size, kp_angle, kp_response, kp_octave, desc, cap, n_out);

@@ -211,6 +211,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
                    ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws, ctx->ransac_ws };
     for (void* p : ps) if (p) (void)hipFree(p);
     orb_ws_free(ctx->orb);
+    pose_alt_free(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->slot_words) (void)hipHostFree(ctx->slot_words);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -585,7 +586,7 @@ extern "C" int vo_sgbm_compute(vo_ctx* ctx, int slot, int16_t* disp16_out)
     if ((rc = slot_wait(ctx, f))) return rc;
     rc = sgbm_run(ctx, f.left, f.right, f.w, f.h, f.disp16);
     if (rc) return rc;
-    f.has_disp = true; f.kp_pending = false;
+    f.has_disp = true; f.kp_pending = false; f.has_kp = false;
     if (disp16_out) {
         VO_HIP(ctx, hipMemcpyAsync(disp16_out, f.disp16, (size_t)f.w * f.h * 2, hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -158,6 +158,22 @@ struct vo_ctx {
     double* red = nullptr;         // reduction scratch
     uint8_t* clique_ws = nullptr;
     size_t clique_ws_bytes = 0;
+    // asynchronous pose steps (vo_pose_pair_begin / _end): two alternates of the match / pose scratch above,
+    // each with its own stream, a pinned result record and a completion event
+    static const int N_POSE_ALT = 3;
+    struct PoseAlt {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        void* result = nullptr;        // pinned PoseOut
+        bool ready = false, busy = false;
+        int slot_a = -1, slot_b = -1;
+        double params[4] = {0, 0, 0, 0};   // ratio, min_matches, rigidity_thr, outlier_thr
+        int32_t *m_idx = nullptr, *m_count = nullptr, *m_dist = nullptr, *mq_idx = nullptr, *mt_idx = nullptr;
+        float *pts_a = nullptr, *pts_b = nullptr, *xy_a = nullptr, *xy_b = nullptr;
+        uint8_t *st_a = nullptr, *st_b = nullptr, *clique_ws = nullptr;
+        size_t clique_ws_bytes = 0;
+    } pose_alt[N_POSE_ALT];
+    int pose_next = 0;
     uint8_t* ransac_ws = nullptr;
     size_t ransac_ws_bytes = 0;
     float* img3_ws = nullptr;
@@ -221,6 +237,7 @@ int xfer_flush(vo_ctx* ctx);
 // make the main stream wait for a slot whose look-ahead work may still be running
 int slot_wait(vo_ctx* ctx, FrameSlot& f);
 int orb_slot_enqueue(vo_ctx* ctx, FrameSlot& f, int nfeatures, int mask_mode, int min_disp16, int max_disp16);
+void pose_alt_free(vo_ctx* ctx);
 
 // implemented in the per-stage files
 int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);

@@ -233,6 +233,7 @@ class ORB:
 
     def __init__(self, ctx, nfeatures=500):
         self._ctx, self.nfeatures = ctx, int(nfeatures)
+        self.last_slot_args = None      # (nfeatures, mask_mode, lo16, hi16) of the latest device-side extraction
 
     def detectAndCompute(self, image, mask=None):
         frame = None
@@ -243,6 +244,7 @@ class ORB:
             frame.materialize_keypoints()     # an earlier list of this frame must not see the new extraction
             if mask is None:
                 self._ctx.lookahead_orb(self.nfeatures, 0, 0, 0)
+                self.last_slot_args = (self.nfeatures, 0, 0, 0)
                 n = self._ctx.orb_slot_count(frame.slot, self.nfeatures, 0)
             else:
                 # d >= lo and d <= hi on d = disp16/16 (exact in float32) <=> integer compare
@@ -251,6 +253,7 @@ class ORB:
                 hi16 = int(np.floor(float(np.float32(mask.hi)) * 16.0))
                 # frames prefetched from here on get their keypoints extracted right behind their SGBM
                 self._ctx.lookahead_orb(self.nfeatures, 1, lo16, hi16)
+                self.last_slot_args = (self.nfeatures, 1, lo16, hi16)
                 n = self._ctx.orb_slot_count(frame.slot, self.nfeatures, 1, lo16, hi16)
             if n == 0:
                 return (), None

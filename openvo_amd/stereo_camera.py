@@ -151,6 +151,10 @@ class StereoCamera:
         self._slot_owner[slot] = _RESERVED
         return SubmittedPair(slot, shape, preprocessed)
 
+    def next_lookahead_slots(self, k=2):
+        """Device slots of the staged pairs expected next (oldest unconsumed look-ahead first)."""
+        return [h[1] for h in self._lookahead[:k]]
+
     def reset_lookahead(self):
         """Drop look-ahead work that has been started but not consumed (its slots are released and
         the pairs will be recomputed when asked for)."""

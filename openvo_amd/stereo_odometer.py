@@ -47,6 +47,8 @@ class StereoOdometer:
         self.c_T_w = np.eye(4)       # world frame expressed in the camera frame
         self.c_T_w_prev = np.eye(4)
         self.skip_cause = ""
+        self._specs = {}             # (slot_a, slot_b, params) -> ticket of a pose step started ahead of time
+        self._next_hint = ()         # SubmittedPairs expected by the next update() calls (set by run())
 
     # ------------------------------------------------------------------------------------------
     def feature_mask(self, disparity):
@@ -118,7 +120,49 @@ class StereoOdometer:
             return False
         self.skipped_frames = 0
         self.save_frame_update(next_img, next_disp, next_3d, next_kps, next_desc)
+        self._start_next_pose()
         return True
+
+    def _pose_params(self):
+        return (float(self.match_threshold), int(self.min_matches), float(max(self.rigidity_threshold, 0)),
+                float(max(self.outlier_threshold, 0)))
+
+    def _fused_ok(self):
+        return (type(self) is StereoOdometer and type(self.matcher) is BFMatcher and self.pose_method == "umeyama"
+                and not any(n in self.__dict__ for n in self._SEAMS))
+
+    def _drop_specs(self, keep=()):
+        for key in [k for k in self._specs if k not in keep]:
+            try:
+                self._ctx.pose_pair_end(self._specs[key])
+            finally:
+                del self._specs[key]
+
+    def _start_next_pose(self):
+        """The frame just accepted is the new `current`.  If the pairs that will come next are already on the
+        device (look-ahead / submitted ahead), start their matching + pose steps now on streams of their own:
+        (current, next) and -- expecting `next` to be accepted as well -- (next, next+1), so that two frame
+        periods hide the latency of the short kernel chain.  Purely an ordering change: _pair_fused looks a
+        step up by its slots and parameters and computes on the spot when the guess was wrong."""
+        if not self._fused_ok() or self.orb.last_slot_args is None:
+            return self._drop_specs()
+        kps = self.current_kps
+        if not self._on_device(kps, self.current_desc, self.current_3d):
+            return self._drop_specs()
+        nxt = [h.slot for h in self._next_hint] if self._next_hint else self.stereo.next_lookahead_slots(2)
+        chain, counts = [kps.frame.slot], [len(kps)]
+        for s in nxt[:2]:
+            if s is None:
+                break
+            chain.append(s)
+            counts.append(self._ctx.orb_slot_count(s, *self.orb.last_slot_args))   # waits for that pair's look-ahead work
+        params = self._pose_params()
+        wanted = [(chain[j], chain[j + 1], params) for j in range(len(chain) - 1)
+                  if 0 < counts[j] <= 3800 and counts[j + 1] >= max(2, self.min_matches)]
+        self._drop_specs(keep=wanted)
+        for key in wanted:
+            if key not in self._specs:
+                self._specs[key] = self._ctx.pose_pair_begin(key[0], key[1], *params)
 
     def run(self, pairs, depth=None):
         """Feed an iterable of host (left, right) pairs through update(), keeping up to `depth` pairs
@@ -135,7 +179,12 @@ class StereoOdometer:
                 queue.append(self.stereo.submit(nxt[0], nxt[1], preprocessed=self.preprocessed_frames))
             if not queue:
                 return
-            yield self.update(queue.popleft(), None)
+            head = queue.popleft()
+            self._next_hint = tuple(queue)[:2]
+            try:
+                yield self.update(head, None)
+            finally:
+                self._next_hint = ()
 
     _SEAMS = ("point_clouds", "point_cloud_transform", "rigid_body_filter", "bilinear_interpolate_pixels",
               "_estimate", "_gate")
@@ -182,8 +231,12 @@ class StereoOdometer:
         """point_clouds + point_cloud_transform in one native call (one device synchronisation);
         same decisions and skip_cause strings as the two methods."""
         from ._native import VoError
-        counts, rc, _, T34 = self._ctx.pose_pair(slot_a, slot_b, self.match_threshold, self.min_matches,
-                                                 max(self.rigidity_threshold, 0), max(self.outlier_threshold, 0))
+        params = self._pose_params()
+        ticket = self._specs.pop((slot_a, slot_b, params), None)
+        if ticket is not None:
+            counts, rc, _, T34 = self._ctx.pose_pair_end(ticket)         # started by an earlier update()
+        else:
+            counts, rc, _, T34 = self._ctx.pose_pair(slot_a, slot_b, *params)
         M, n1, n2, flags = (int(v) for v in counts)
         if M < self.min_matches:
             self.skip_cause = "matches"

@@ -300,3 +300,28 @@ def test_lookahead_keypoints_are_recomputed_when_the_request_differs():
         kr, dr = o.orb.detectAndCompute(leftb, o.feature_mask(dispb))
         assert len(k) == len(kr) and np.array_equal(k.xy, kr.xy) and np.array_equal(d, dr)
     assert len(kps300) < len(kps500)
+
+
+def test_pose_started_ahead_survives_a_change_of_plan():
+    """The matching + pose step of the next pairs is started ahead of time when they are already on the
+    device; results must not depend on it.  Here the caller breaks the expected order (skips a staged
+    pair, then changes a threshold) and every pose must equal the one of an odometer that never looks ahead."""
+    c, cam = _rig("C1", max_keypoints=500)
+    frames = c.pairs(0, 10)
+    kw = dict(preprocessed_frames=True, rigidity_threshold=0.1, outlier_threshold=0.02)
+    order = [0, 1, 2, 4, 5, 3, 6, 7, 9]
+    c2, cam2 = _rig("C1", max_keypoints=500)
+    cam2.lookahead = 0
+    ref = StereoOdometer(cam2, **kw)
+    want = []
+    for j, i in enumerate(order):
+        if j == 6:
+            ref.match_threshold = 0.75
+        want.append((ref.update(*frames[i]), ref.c_T_w.copy()))
+    staged = cam.stage_pairs(frames)
+    odo = StereoOdometer(cam, **kw)
+    for j, i in enumerate(order):
+        if j == 6:
+            odo.match_threshold = 0.75
+        ok = odo.update(staged[i], None)
+        assert ok == want[j][0] and np.array_equal(odo.c_T_w, want[j][1]), (j, i)
