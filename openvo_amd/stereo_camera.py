@@ -72,6 +72,7 @@ class StereoCamera:
         self._ctx.set_roi(vr[0], vr[1], vr[2], vr[3])
         self.stereoSGBM = StereoSGBM(self._ctx, sgbm_params)
         self._slot_owner = [None] * _native.VO_NUM_SLOTS   # weak bookkeeping: FrameHandle per slot
+        self._slot_gen = [0] * _native.VO_NUM_SLOTS        # bumped whenever a slot receives a new pair
         self._next_slot = 0
         # staged pairs: how many following pairs run their SGBM ahead (0..4; env VO_LOOKAHEAD overrides)
         self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "7"))
@@ -148,8 +149,13 @@ class StereoCamera:
         if slot is None:
             return SubmittedPair(None, None, preprocessed, (img_left.copy(), img_right.copy()))
         shape = self._ctx.prefetch_pair(slot, img_left, img_right, preprocessed)
+        self._slot_gen[slot] += 1
         self._slot_owner[slot] = _RESERVED
         return SubmittedPair(slot, shape, preprocessed)
+
+    def slot_key(self, slot):
+        """(slot, generation): identifies the pair a slot holds right now."""
+        return (slot, self._slot_gen[slot])
 
     def next_lookahead_slots(self, k=2):
         """Device slots of the staged pairs expected next (oldest unconsumed look-ahead first)."""
@@ -224,6 +230,7 @@ class StereoCamera:
                 self._slot_owner[hit[1]] = None          # stale prediction: give the slot back
         if slot is None:
             slot, _ = self._acquire_slot()
+            self._slot_gen[slot] += 1
             if staged:
                 w, h = self._ctx.load_staged_pair(slot, img_left.index, preprocessed)
             else:
@@ -246,6 +253,7 @@ class StereoCamera:
                 if nxt is None:
                     break
                 shape = self._ctx.prefetch_staged_pair(nxt, idx, preprocessed)
+                self._slot_gen[nxt] += 1
                 self._slot_owner[nxt] = _RESERVED
                 self._lookahead.append(((idx, bool(preprocessed)), nxt, shape))
         return DeviceImage(frame, "xyz"), DeviceImage(frame, "disp"), DeviceImage(frame, "left")

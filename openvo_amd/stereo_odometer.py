@@ -47,7 +47,7 @@ class StereoOdometer:
         self.c_T_w = np.eye(4)       # world frame expressed in the camera frame
         self.c_T_w_prev = np.eye(4)
         self.skip_cause = ""
-        self._specs = {}             # (slot_a, slot_b, params) -> ticket of a pose step started ahead of time
+        self._specs = {}             # (slot key a, slot key b, params) -> ticket of a pose step started ahead of time
         self._next_hint = ()         # SubmittedPairs expected by the next update() calls (set by run())
 
     # ------------------------------------------------------------------------------------------
@@ -157,12 +157,13 @@ class StereoOdometer:
             chain.append(s)
             counts.append(self._ctx.orb_slot_count(s, *self.orb.last_slot_args))   # waits for that pair's look-ahead work
         params = self._pose_params()
-        wanted = [(chain[j], chain[j + 1], params) for j in range(len(chain) - 1)
+        sk = self.stereo.slot_key       # slot + generation: a slot refilled with another pair never matches
+        wanted = [(sk(chain[j]), sk(chain[j + 1]), params) for j in range(len(chain) - 1)
                   if 0 < counts[j] <= 3800 and counts[j + 1] >= max(2, self.min_matches)]
         self._drop_specs(keep=wanted)
         for key in wanted:
             if key not in self._specs:
-                self._specs[key] = self._ctx.pose_pair_begin(key[0], key[1], *params)
+                self._specs[key] = self._ctx.pose_pair_begin(key[0][0], key[1][0], *params)
 
     def run(self, pairs, depth=None):
         """Feed an iterable of host (left, right) pairs through update(), keeping up to `depth` pairs
@@ -232,7 +233,7 @@ class StereoOdometer:
         same decisions and skip_cause strings as the two methods."""
         from ._native import VoError
         params = self._pose_params()
-        ticket = self._specs.pop((slot_a, slot_b, params), None)
+        ticket = self._specs.pop((self.stereo.slot_key(slot_a), self.stereo.slot_key(slot_b), params), None)
         if ticket is not None:
             counts, rc, _, T34 = self._ctx.pose_pair_end(ticket)         # started by an earlier update()
         else:

@@ -325,3 +325,23 @@ def test_pose_started_ahead_survives_a_change_of_plan():
             odo.match_threshold = 0.75
         ok = odo.update(staged[i], None)
         assert ok == want[j][0] and np.array_equal(odo.c_T_w, want[j][1]), (j, i)
+
+
+def test_pose_started_ahead_is_never_reused_for_a_refilled_slot():
+    """Dropping the look-ahead (slots get refilled with other pairs) must invalidate pose steps that were
+    started ahead of time on the old contents."""
+    c, cam = _rig("C1", max_keypoints=500)
+    frames = c.pairs(0, 12)
+    kw = dict(preprocessed_frames=True, rigidity_threshold=0.1, outlier_threshold=0.02)
+    c2, cam2 = _rig("C1", max_keypoints=500)
+    cam2.lookahead = 0
+    ref = StereoOdometer(cam2, **kw)
+    order = [0, 1, 2, 3, 8, 9, 10, 11]          # jump after the look-ahead has been dropped
+    want = [(ref.update(*frames[i]), ref.c_T_w.copy()) for i in order]
+    staged = cam.stage_pairs(frames)
+    odo = StereoOdometer(cam, **kw)
+    for j, i in enumerate(order):
+        if j == 4:
+            cam.reset_lookahead()
+        ok = odo.update(staged[i], None)
+        assert ok == want[j][0] and np.array_equal(odo.c_T_w, want[j][1]), (j, i)
