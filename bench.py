@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--from-host", action="store_true",
                     help="diagnostic: hand host numpy images to the odometer every step (StereoOdometer.run: pinned "
                          "staging + async upload ahead) instead of HBM-resident inputs -- the PCIe-inclusive rate")
+    ap.add_argument("--ndisp", type=int, default=0, help="diagnostic: override numDisparities (changes the workload!)")
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs the CPU oracle is timed on (0 = skip)")
     args = ap.parse_args()
 
@@ -75,6 +76,8 @@ def main():
     c = Corridor(args.workload)
     # config 4 is the 8-path (MODE_HH) cost-volume stress case; every other workload runs the reference's 5-path default
     sgbm = c.sgbm_params(mode=1) if args.workload == "C4" else c.sgbm_params()
+    if args.ndisp:
+        sgbm["numDisparities"] = args.ndisp
     cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), sgbm, (c.w, c.h),
                        device=(local_rank if (world == 1 or use_cuda) else local_rank % max(ndev, 1)),
                        max_keypoints=ODO_KW["nfeatures"])

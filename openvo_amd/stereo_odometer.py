@@ -161,9 +161,13 @@ class StereoOdometer:
         wanted = [(sk(chain[j]), sk(chain[j + 1]), params) for j in range(len(chain) - 1)
                   if 0 < counts[j] <= 3800 and counts[j + 1] >= max(2, self.min_matches)]
         self._drop_specs(keep=wanted)
+        from ._native import VoError
         for key in wanted:
             if key not in self._specs:
-                self._specs[key] = self._ctx.pose_pair_begin(key[0][0], key[1][0], *params)
+                try:
+                    self._specs[key] = self._ctx.pose_pair_begin(key[0][0], key[1][0], *params)
+                except VoError:
+                    pass                     # nothing started: update() computes the step when it gets there
 
     def run(self, pairs, depth=None):
         """Feed an iterable of host (left, right) pairs through update(), keeping up to `depth` pairs
