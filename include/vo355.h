@@ -34,8 +34,8 @@ enum {
     VO_E_NUMERIC = -5  /* degenerate input (Umeyama: <3 points / colinear) */
 };
 
-#define VO_NUM_SLOTS 10 /* frame slots per context: the odometer keeps prev, current, next; two more
-                          may hold look-ahead pairs */
+#define VO_NUM_SLOTS 10 /* frame slots per context: the odometer keeps prev and current, up to 7 more hold
+                           look-ahead pairs (vo_prefetch_*), one is spare */
 
 /* lifetime ------------------------------------------------------------------------- */
 int vo_create(int device_id, int max_w, int max_h, int max_disp, int max_kp, vo_ctx** out);

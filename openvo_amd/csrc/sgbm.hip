@@ -7,19 +7,25 @@
 //   planesL[y][x]        2 x u32  : (u,u0,u1) bytes of the x-Sobel channel, then of the raw channel
 //   planesR[k][y][p]     u32      : plane k of (v,v0,v1)x2, packed as value(p) | value(p-1) << 16
 //   C[y][x1][Dp]         int16    : block cost (+P2), d fastest, Dp = D rounded up to 32, x1 = x - minX1
-//   L[dir][y][x1][Dp]    int16    : one aggregated volume per path direction
+//   L[dir][y][x1][Dp]    int16    : one aggregated volume per STORED path direction (all but the top-down
+//                                   vertical one, which only ever lives in registers)
 // Kernels
 //   k_sgbm_planes  prefilter + Birchfield-Tomasi half-pixel bounds (elementwise)
 //   k_sgbm_cost_sweep  BT pixel cost + (2*SW2+1)^2 box sum; one lane = one disparity PAIR in packed
 //                  int16x2 math; right-image planes travel through DPP lane-shift chains, the horizontal
 //                  window slides in registers, the vertical one through an LDS ring; writes C once
-//   k_sgbm_paths   ALL path directions in one launch.  A scan line lives in one 16-lane DPP row
+//   k_sgbm_paths   every stored path direction in one launch.  A scan line lives in one 16-lane DPP row
 //                  (each lane holds Dp/16 consecutive disparities in packed registers), so a wave
 //                  advances 4 independent lines; neighbours d-1/d+1 come from row_shr/row_shl
 //                  (row ends are the MAX_COST sentinels for free), the min over d is a 4-step
-//                  row_ror all-reduce.  Reads C once per direction, writes that direction's L.
-//   k_sgbm_wta     per pixel (16 lanes): S = sat-sum of the L volumes, first minimum, uniqueness,
-//                  sub-pixel, disp2 via atomicMin on (cost, scan order) keys
+//                  row_ror all-reduce.  Reads C once per direction, writes that direction's L with
+//                  non-temporal stores (single use; C must stay cached for the other directions).
+//   k_sgbm_vwta    the top-down vertical direction fused with the WTA: a wave walks 4 columns, per row it
+//                  reads C and the stored L volumes, advances its own path in registers, sums, picks the
+//                  first minimum and tests uniqueness; leaves a 2-word record per pixel
+//   k_sgbm_fin     records -> sub-pixel disp1 + disp2 candidates via atomicMin on (cost, scan order) keys
+//   k_sgbm_wta     unfused fallback (VO_FUSE_WTA=0, uniquenessRatio >= 100): per pixel (16 lanes) S = sat-sum
+//                  of all L volumes, same winner logic inline
 //   k_sgbm_lr      left-right consistency check
 //   k_median3, k_ccl_* : medianBlur(3) and filterSpeckles (run-based union-find labelling)
 #include "vo_internal.h"
