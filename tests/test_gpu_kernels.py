@@ -228,3 +228,23 @@ def test_solve_pnp_ransac_wrapper(ctx_small):
     assert np.abs(Rg - R).max() < 3e-3 and np.abs(tg - t).max() < 3e-2 and info["best_count"] >= 0.7 * 800
     with pytest.raises(Exception):
         ctx_small.ransac_pnp(X[:3], uv[:3], K4, 10)
+
+
+@pytest.mark.parametrize("w,h,ndisp,mind", [(333, 201, 48, 0), (621, 187, 64, -8), (257, 129, 16, 3)])
+def test_odd_image_sizes_sgbm_and_orb(oracle, ctx_small, w, h, ndisp, mind):
+    """Widths / heights that are multiples of nothing (KITTI's 1241x376 halves to 621x187): SGBM disparity
+    and ORB keypoints + descriptors stay bit-exact."""
+    c, L, R = _pair("C1", 4)
+    L, R = np.ascontiguousarray(L[:h, :w]), np.ascontiguousarray(R[:h, :w])
+    p = dict(minDisparity=mind, numDisparities=ndisp, blockSize=5, P1=200, P2=800, disp12MaxDiff=1, preFilterCap=63,
+             uniquenessRatio=10, speckleWindowSize=100, speckleRange=2)
+    for mode in (0, 1):
+        ctx_small.set_sgbm(p, mode)
+        got = ctx_small.sgbm_compute_host(L, R)
+        ref = oracle.sgbm_compute(L, R, p, mode)
+        assert np.array_equal(got, ref), "mode %d: %d pixels differ" % (mode, int((got != ref).sum()))
+    g = ctx_small.orb_host(L, None, 300)
+    r = oracle.orb_detect_and_compute(L, None, 300)
+    assert len(g["xy"]) == len(r["xy"]) > 50
+    assert np.array_equal(g["xy"].view(np.uint32), r["xy"].view(np.uint32)) and np.array_equal(g["desc"], r["desc"])
+    assert np.array_equal(g["angle"].view(np.uint32), r["angle"].view(np.uint32)) and np.array_equal(g["octave"], r["octave"])
