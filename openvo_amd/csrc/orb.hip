@@ -297,12 +297,10 @@ __global__ void k_orb_nms(const LevelsDev* __restrict__ L, const uint8_t* __rest
 }
 
 // retainBest(2*quota) by FAST score: keep every candidate whose score >= the n-th largest
-__global__ void __launch_bounds__(1024) k_orb_fast_select(const LevelsDev* __restrict__ L, const int32_t* __restrict__ cand_pos,
-                                                          const float* __restrict__ cand_resp, int32_t* __restrict__ candA_pos,
-                                                          int32_t* __restrict__ cnt)
+__device__ __forceinline__ void orb_fast_select(const LevelsDev* L, const int32_t* cand_pos,
+                                                const float* cand_resp, int32_t* candA_pos,
+                                                int32_t* cnt, int* s_hist, int& s_thr, int& s_n)
 {
-    __shared__ int s_hist[256];
-    __shared__ int s_thr, s_n;
     const int lvl = blockIdx.x;
     const LevelDev d = L->l[lvl];
     const int n = cnt[CNT_CAND + lvl], keep = 2 * d.quota;
@@ -343,15 +341,10 @@ __global__ void __launch_bounds__(1024) k_orb_fast_select(const LevelsDev* __res
     if (threadIdx.x == 0) cnt[CNT_A + lvl] = s_n;
 }
 
-// Harris response (7x7 block) on the unblurred level
-__global__ void k_orb_harris(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg,
-                             const int32_t* __restrict__ candA_pos, float* __restrict__ candA_resp,
-                             const int32_t* __restrict__ cnt)
+// Harris response (7x7 block) on the unblurred level, candidate i of this block's level
+__device__ __forceinline__ void orb_harris_one(const LevelDev& d, const uint8_t* pimg,
+                                               const int32_t* candA_pos, float* candA_resp, int i)
 {
-    const int lvl = blockIdx.y;
-    const LevelDev d = L->l[lvl];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cnt[CNT_A + lvl]) return;
     const int pos = candA_pos[d.cand_off + i];
     const int w = d.w;
     const uint8_t* c = pimg + d.off + pos;
@@ -379,14 +372,12 @@ __device__ __forceinline__ unsigned f2key(float f)
 
 // retainBest(quota) by Harris response (radix select of the quota-th largest, ties kept), then
 // sort the survivors by position and stage them per level
-__global__ void __launch_bounds__(1024) k_orb_harris_select(const LevelsDev* __restrict__ L, const int32_t* __restrict__ candA_pos,
-                                                            const float* __restrict__ candA_resp, int32_t* __restrict__ fin_pos,
-                                                            float* __restrict__ fin_resp, int32_t* __restrict__ tmp_pos,
-                                                            float* __restrict__ tmp_resp, int32_t* __restrict__ cnt)
+__device__ __forceinline__ void orb_harris_select(const LevelsDev* L, const int32_t* candA_pos,
+                                                  const float* candA_resp, int32_t* fin_pos,
+                                                  float* fin_resp, int32_t* tmp_pos,
+                                                  float* tmp_resp, int32_t* cnt, int* hist,
+                                                  unsigned& s_prefix, unsigned& s_mask, int& s_remaining, int& s_nf)
 {
-    __shared__ int hist[256];
-    __shared__ unsigned s_prefix, s_mask;
-    __shared__ int s_remaining, s_nf;
     const int lvl = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const LevelDev d = L->l[lvl];
     const int n = cnt[CNT_A + lvl], keep = d.quota;
@@ -440,6 +431,27 @@ __global__ void __launch_bounds__(1024) k_orb_harris_select(const LevelsDev* __r
         fin_resp[d.cand_off + rank] = tr[i];
     }
     if (tid == 0) cnt[CNT_FIN + lvl] = nf;
+}
+
+// One block per pyramid level runs the whole selection: retainBest(2*quota) by FAST score -> Harris response
+// of the survivors -> retainBest(quota) by Harris + canonical order.  (Three launches with a mostly empty
+// grid in the middle before; the phases only ever needed block-level synchronisation.)
+// (fin_* alias cand_*: the final lists replace the NMS lists, which are dead by then -- no __restrict__ here)
+__global__ void __launch_bounds__(1024) k_orb_select(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg,
+                                                     const int32_t* cand_pos, const float* cand_resp,
+                                                     int32_t* candA_pos, float* candA_resp, int32_t* fin_pos, float* fin_resp,
+                                                     int32_t* tmp_pos, float* tmp_resp, int32_t* cnt)
+{
+    __shared__ int s_hist[256];
+    __shared__ int s_thr, s_n, s_remaining, s_nf;
+    __shared__ unsigned s_prefix, s_mask;
+    orb_fast_select(L, cand_pos, cand_resp, candA_pos, cnt, s_hist, s_thr, s_n);
+    __syncthreads();
+    const LevelDev d = L->l[blockIdx.x];
+    const int nA = s_n;
+    for (int i = threadIdx.x; i < nA; i += blockDim.x) orb_harris_one(d, pimg, candA_pos, candA_resp, i);
+    __syncthreads();
+    orb_harris_select(L, candA_pos, candA_resp, fin_pos, fin_resp, tmp_pos, tmp_resp, cnt, s_hist, s_prefix, s_mask, s_remaining, s_nf);
 }
 
 // concatenate the levels into the slot's keypoint arrays
@@ -632,14 +644,10 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
     hipLaunchKernelGGL(k_orb_fast, dim3(div_up(w, 64), h, NL), dim3(64), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.pyr_score);
     hipLaunchKernelGGL(k_orb_nms, dim3(div_up(w - 2 * EDGE, 64), div_up(h - 2 * EDGE, 16), NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_score,
                        ctx->orb.pyr_mask, with_mask, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.counters);
-    hipLaunchKernelGGL(k_orb_fast_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.candA_pos, ctx->orb.counters);
-    // upper bound of the Harris work list: every candidate of level 0
-    const int maxA = ((w + 1) / 2) * ((h + 1) / 2);
-    hipLaunchKernelGGL(k_orb_harris, dim3(div_up(maxA, 256), NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.candA_pos,
-                       ctx->orb.candA_resp, ctx->orb.counters);
     // after the select, cand_* hold the per-level final lists; candB_* are scratch
-    hipLaunchKernelGGL(k_orb_harris_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orb.candA_pos, ctx->orb.candA_resp, ctx->orb.cand_pos,
-                       ctx->orb.cand_resp, ctx->orb.candB_pos, ctx->orb.candB_resp, ctx->orb.counters);
+    hipLaunchKernelGGL(k_orb_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.cand_pos, ctx->orb.cand_resp,
+                       ctx->orb.candA_pos, ctx->orb.candA_resp, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.candB_pos,
+                       ctx->orb.candB_resp, ctx->orb.counters);
     hipLaunchKernelGGL(k_orb_pack, dim3(div_up(ctx->kp_cap, 256), NL), dim3(256), 0, ctx->stream, dL, ctx->orb.cand_pos, ctx->orb.cand_resp,
                        ctx->orb.counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, ctx->orb.kp_pos);
     hipLaunchKernelGGL(k_orb_blur_h, dim3(div_up(w, 256), h, NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.pyr_tmp16);
