@@ -235,43 +235,46 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int 
     return -b0 - 1;
 }
 
-__global__ void k_orb_fast(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg, uint8_t* __restrict__ pscore)
+// FAST score + 3x3 non-max suppression (strict >) + pixel mask + image border in one pass; survivors are
+// appended per level.  Block = 4 waves, tile = 64 columns x 16 rows of the border-free interior: the scores
+// of the tile and its 1-pixel halo go through LDS only (no score image), wave w then judges rows 4w..4w+3.
+// The survivors of the whole tile reserve their slots with ONE returning global atomic (a per-wave atomic
+// on a single counter serialises at ~12 ns each).
+__global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg,
+                                                      const uint8_t* __restrict__ pmask, int with_mask, int32_t* __restrict__ cand_pos,
+                                                      float* __restrict__ cand_resp, int32_t* __restrict__ cnt)
 {
-    const LevelDev d = L->l[blockIdx.z];
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= d.w || y >= d.h) return;
-    int s = 0;
-    if (x >= 3 && x < d.w - 3 && y >= 3 && y < d.h - 3) s = fast_score_at(pimg + d.off + (size_t)y * d.w + x, d.w);
-    pscore[d.off + (size_t)y * d.w + x] = (uint8_t)s;
-}
-
-// 3x3 non-max suppression (strict >), pixel mask, image border; survivors appended per level
-__global__ void k_orb_nms(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pscore,
-                          const uint8_t* __restrict__ pmask, int with_mask, int32_t* __restrict__ cand_pos,
-                          float* __restrict__ cand_resp, int32_t* __restrict__ cnt)
-{
-    // block = 4 waves, tile = 64 columns x 16 rows (wave w takes rows 4w..4w+3).  The survivors of
-    // the whole tile reserve their slots with ONE returning global atomic (a per-wave atomic on a
-    // single counter serialises at ~12 ns each and dominated this kernel).
+    constexpr int TW = 64, TH = 16, SW = TW + 2, SH = TH + 2, SP = SW + 2;   // padded LDS row
+    __shared__ uint8_t s_sc[SH * SP];
     __shared__ int s_cnt[16];
     __shared__ int s_base;
     const int lvl = blockIdx.z;
     const LevelDev d = L->l[lvl];
     if (d.w <= 2 * EDGE || d.h <= 2 * EDGE) return;  // block-uniform (depends on the level only)
+    const int x0 = blockIdx.x * TW + EDGE, y0 = blockIdx.y * TH + EDGE;
+    if (x0 >= d.w - EDGE || y0 >= d.h - EDGE) return;  // block-uniform
+    const int xlim = d.w - EDGE + 1, ylim = d.h - EDGE + 1;   // scores are needed up to one pixel past the interior
+    const uint8_t* img = pimg + d.off;
+    for (int i = threadIdx.x; i < SW * SH; i += blockDim.x) {
+        const int ty = i / SW, tx = i - ty * SW;
+        const int x = x0 - 1 + tx, y = y0 - 1 + ty;
+        int s = 0;
+        if (x < xlim && y < ylim) s = fast_score_at(img + (size_t)y * d.w + x, d.w);   // x, y >= EDGE - 1 >= 3 always
+        s_sc[ty * SP + tx] = (uint8_t)s;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane + EDGE;
-    if (blockIdx.x * 64 + EDGE >= d.w - EDGE || blockIdx.y * 16 + EDGE >= d.h - EDGE) return;  // block-uniform
+    const int x = x0 + lane;
     int sc[4];
     unsigned long long bal[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int y = blockIdx.y * 16 + wv * 4 + r + EDGE;
+        const int ty = wv * 4 + r, y = y0 + ty;
         int s = 0;
         if (x < d.w - EDGE && y < d.h - EDGE) {
-            const uint8_t* q = pscore + d.off + (size_t)y * d.w + x;
-            const int w = d.w;
+            const uint8_t* q = s_sc + (ty + 1) * SP + lane + 1;
             s = q[0];
-            if (s && !(s > q[-1] && s > q[1] && s > q[-w - 1] && s > q[-w] && s > q[-w + 1] && s > q[w - 1] && s > q[w] && s > q[w + 1])) s = 0;
+            if (s && !(s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] && s > q[SP] && s > q[SP + 1])) s = 0;
             if (s && with_mask && pmask[d.off + (size_t)y * d.w + x] == 0) s = 0;
         }
         sc[r] = s;
@@ -288,7 +291,7 @@ __global__ void k_orb_nms(const LevelsDev* __restrict__ L, const uint8_t* __rest
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         if (sc[r]) {
-            const int y = blockIdx.y * 16 + wv * 4 + r + EDGE;
+            const int y = y0 + wv * 4 + r;
             const int slot = s_base + s_cnt[wv * 4 + r] + __popcll(bal[r] & ((1ull << lane) - 1ull));
             cand_pos[d.cand_off + slot] = y * d.w + x;
             cand_resp[d.cand_off + slot] = (float)sc[r];
@@ -641,9 +644,8 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
     for (int l = 1; l < NL; l++)
         hipLaunchKernelGGL(k_orb_resize, dim3(div_up(Lh->l[l].w, 256), Lh->l[l].h), dim3(256), 0, ctx->stream, dL, l, ctx->rs_ofs,
                            ctx->rs_coef, ctx->orb.pyr_img, ctx->orb.pyr_mask, with_mask);
-    hipLaunchKernelGGL(k_orb_fast, dim3(div_up(w, 64), h, NL), dim3(64), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.pyr_score);
-    hipLaunchKernelGGL(k_orb_nms, dim3(div_up(w - 2 * EDGE, 64), div_up(h - 2 * EDGE, 16), NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_score,
-                       ctx->orb.pyr_mask, with_mask, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.counters);
+    hipLaunchKernelGGL(k_orb_fast_nms, dim3(div_up(w - 2 * EDGE, 64), div_up(h - 2 * EDGE, 16), NL), dim3(256), 0, ctx->stream, dL,
+                       ctx->orb.pyr_img, ctx->orb.pyr_mask, with_mask, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.counters);
     // after the select, cand_* hold the per-level final lists; candB_* are scratch
     hipLaunchKernelGGL(k_orb_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.cand_pos, ctx->orb.cand_resp,
                        ctx->orb.candA_pos, ctx->orb.candA_resp, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.candB_pos,
