@@ -487,36 +487,7 @@ __global__ void k_orb_pack(const LevelsDev* __restrict__ L, const int32_t* __res
 // kernel round(256*g) = [18,34,49,55,49,34,18], row pass exact in 16 bits, column pass
 // (sum + 2^15) >> 16 saturated.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ int reflect101(int p, int len)
-{
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
-    return p;
-}
 __constant__ int c_gk[7] = { 18, 34, 49, 55, 49, 34, 18 };
-
-__global__ void k_orb_blur_h(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg, uint16_t* __restrict__ tmp)
-{
-    const LevelDev d = L->l[blockIdx.z];
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= d.w || y >= d.h) return;
-    const uint8_t* r = pimg + d.off + (size_t)y * d.w;
-    int s = 0;
-#pragma unroll
-    for (int i = -3; i <= 3; i++) s += c_gk[i + 3] * r[reflect101(x + i, d.w)];
-    tmp[d.off + (size_t)y * d.w + x] = (uint16_t)s;
-}
-__global__ void k_orb_blur_v(const LevelsDev* __restrict__ L, const uint16_t* __restrict__ tmp, uint8_t* __restrict__ pblur)
-{
-    const LevelDev d = L->l[blockIdx.z];
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= d.w || y >= d.h) return;
-    int s = 0;
-#pragma unroll
-    for (int i = -3; i <= 3; i++) s += c_gk[i + 3] * (int)tmp[d.off + (size_t)reflect101(y + i, d.h) * d.w + x];
-    s = (s + (1 << 15)) >> 16;
-    pblur[d.off + (size_t)y * d.w + x] = (uint8_t)min(s, 255);
-}
 
 // ---------------------------------------------------------------------------------------
 // orientation (intensity centroid) + rotated BRIEF, one wave per keypoint
@@ -549,8 +520,17 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return v;
 }
 
+// The descriptor samples the 7x7-Gaussian-blurred level (GaussianBlur(7,7,2,2), 8-bit fixed point, row pass
+// to 16 bit then column pass) at rotated pattern points within 18 pixels of the keypoint.  Blurring the whole
+// pyramid for a few hundred keypoints wasted two launches and ~40 M multiply-adds: each wave blurs just its
+// own 39x39 patch into LDS (same two passes, same rounding; the 22-pixel reach stays inside the 31-pixel
+// keypoint border, so no reflection is ever needed).
+#define DESC_R 19
+#define DESC_W (2 * DESC_R + 1)        // 39
+#define DESC_HR (DESC_W + 6)           // 45 rows after the row pass
+#define DESC_LD 40
 __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg,
-                                                     const uint8_t* __restrict__ pblur, const int32_t* __restrict__ cnt, int cap,
+                                                     const int32_t* __restrict__ cnt, int cap,
                                                      const float* __restrict__ kp_xy, const int32_t* __restrict__ kp_oct,
                                                      const int32_t* __restrict__ kp_pos, float* __restrict__ kp_angle,
                                                      uint8_t* __restrict__ desc)
@@ -585,7 +565,30 @@ __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev* __restric
     const float ar = angle * (float)(3.1415926535897932384626433832795 / 180.f);
     const float ca = (float)cos((double)ar), sa = (float)sin((double)ar);
     const int cx = __float2int_rn(kp_xy[2 * k] * iscale), cy = __float2int_rn(kp_xy[2 * k + 1] * iscale);
-    const uint8_t* bc = pblur + d.off + (size_t)cy * w + cx;
+    __shared__ uint16_t s_row[4][DESC_HR * DESC_LD];
+    __shared__ uint8_t s_blur[4][DESC_W * DESC_LD];
+    uint16_t* rowp = s_row[threadIdx.x >> 6];
+    uint8_t* blr = s_blur[threadIdx.x >> 6];
+    const uint8_t* src = pimg + d.off + (size_t)(cy - DESC_R - 3) * w + (cx - DESC_R);
+    for (int i = lane; i < DESC_HR * DESC_W; i += 64) {          // row pass
+        const int r = i / DESC_W, c = i - r * DESC_W;
+        const uint8_t* q = src + (size_t)r * w + c;
+        int sum = 0;
+#pragma unroll
+        for (int t = -3; t <= 3; t++) sum += c_gk[t + 3] * q[t];
+        rowp[r * DESC_LD + c] = (uint16_t)sum;
+    }
+    __builtin_amdgcn_wave_barrier();   // LDS accesses of one wave are served in order
+    for (int i = lane; i < DESC_W * DESC_W; i += 64) {           // column pass
+        const int r = i / DESC_W, c = i - r * DESC_W;
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 7; t++) sum += c_gk[t] * (int)rowp[(r + t) * DESC_LD + c];
+        sum = (sum + (1 << 15)) >> 16;
+        blr[r * DESC_LD + c] = (uint8_t)min(sum, 255);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* bc = blr + DESC_R * DESC_LD + DESC_R;
     if (lane < 32) {
         int val = 0;
 #pragma unroll
@@ -594,7 +597,7 @@ __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev* __restric
             const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
             const int ix0 = __float2int_rn(x0 * ca - y0 * sa), iy0 = __float2int_rn(x0 * sa + y0 * ca);
             const int ix1 = __float2int_rn(x1 * ca - y1 * sa), iy1 = __float2int_rn(x1 * sa + y1 * ca);
-            const int t0 = bc[iy0 * w + ix0], t1 = bc[iy1 * w + ix1];
+            const int t0 = bc[iy0 * DESC_LD + ix0], t1 = bc[iy1 * DESC_LD + ix1];
             val |= (t0 < t1) << b;
         }
         desc[(size_t)k * 32 + lane] = (uint8_t)val;
@@ -652,9 +655,7 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
                        ctx->orb.candB_resp, ctx->orb.counters);
     hipLaunchKernelGGL(k_orb_pack, dim3(div_up(ctx->kp_cap, 256), NL), dim3(256), 0, ctx->stream, dL, ctx->orb.cand_pos, ctx->orb.cand_resp,
                        ctx->orb.counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, ctx->orb.kp_pos);
-    hipLaunchKernelGGL(k_orb_blur_h, dim3(div_up(w, 256), h, NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.pyr_tmp16);
-    hipLaunchKernelGGL(k_orb_blur_v, dim3(div_up(w, 256), h, NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_tmp16, ctx->orb.pyr_blur);
-    hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.pyr_blur,
+    hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img,
                        ctx->orb.counters, ctx->kp_cap, fs->kp_xy, fs->kp_oct, ctx->orb.kp_pos, fs->kp_angle, fs->desc);
     VO_CHECK_LAUNCH(ctx);
     VO_HIP(ctx, hipMemcpyAsync(fs->n_kp_host, ctx->orb.counters + CNT_TOTAL, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -51,10 +51,9 @@ struct FrameSlot {
 
 // scratch of one ORB run (pyramids, candidate lists, counters); one per look-ahead engine
 struct OrbWs {
-    uint8_t *pyr_img = nullptr, *pyr_blur = nullptr, *pyr_mask = nullptr;
+    uint8_t *pyr_img = nullptr, *pyr_mask = nullptr;
     int32_t *cand_pos = nullptr, *candA_pos = nullptr, *candB_pos = nullptr, *kp_pos = nullptr, *counters = nullptr;
     float *cand_resp = nullptr, *candA_resp = nullptr, *candB_resp = nullptr;
-    uint16_t* pyr_tmp16 = nullptr;
     hipEvent_t done = nullptr;   // end of the latest run in this workspace (any stream)
     bool done_valid = false;
 };
