@@ -133,9 +133,10 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h)
 __global__ void k_orb_level0(const uint8_t* __restrict__ img, int img_stride, int w, int h, int mask_mode,
                              const int16_t* __restrict__ disp16, int disp_stride, int min_d16, int max_d16,
                              const uint8_t* __restrict__ mask, int mask_stride, uint8_t* __restrict__ pimg,
-                             uint8_t* __restrict__ pmask)
+                             uint8_t* __restrict__ pmask, int32_t* __restrict__ cnt)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (blockIdx.x == 0 && y == 0 && threadIdx.x < CNT_HIST) cnt[threadIdx.x] = 0;   // the run's counters start here
     if (x >= w) return;
     pimg[(size_t)y * w + x] = img[(size_t)y * img_stride + x];
     if (mask_mode == 1) {
@@ -457,31 +458,6 @@ __global__ void __launch_bounds__(1024) k_orb_select(const LevelsDev* __restrict
     orb_harris_select(L, candA_pos, candA_resp, fin_pos, fin_resp, tmp_pos, tmp_resp, cnt, s_hist, s_prefix, s_mask, s_remaining, s_nf);
 }
 
-// concatenate the levels into the slot's keypoint arrays
-__global__ void k_orb_pack(const LevelsDev* __restrict__ L, const int32_t* __restrict__ fin_pos,
-                           const float* __restrict__ fin_resp, int32_t* __restrict__ cnt, int cap, float* __restrict__ kp_xy,
-                           float* __restrict__ kp_size, float* __restrict__ kp_resp, int32_t* __restrict__ kp_oct,
-                           int32_t* __restrict__ kp_pos)
-{
-    const int lvl = blockIdx.y;
-    const LevelDev d = L->l[lvl];
-    int base = 0;
-    for (int k = 0; k < lvl; k++) base += cnt[CNT_FIN + k];
-    const int nf = cnt[CNT_FIN + lvl];
-    if (lvl == NL - 1 && blockIdx.x == 0 && threadIdx.x == 0) cnt[CNT_TOTAL] = base + nf;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nf || base + i >= cap) return;
-    const int pos = fin_pos[d.cand_off + i];
-    const int x = pos % d.w, y = pos / d.w;
-    const int o = base + i;
-    kp_xy[2 * o] = (float)x * d.scale;
-    kp_xy[2 * o + 1] = (float)y * d.scale;
-    kp_size[o] = 31 * d.scale;
-    kp_resp[o] = fin_resp[d.cand_off + i];
-    kp_oct[o] = lvl;
-    kp_pos[o] = pos;
-}
-
 // ---------------------------------------------------------------------------------------
 // GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) as the sepFilter2D 8-bit path evaluates it:
 // kernel round(256*g) = [18,34,49,55,49,34,18], row pass exact in 16 bits, column pass
@@ -530,18 +506,34 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 #define DESC_HR (DESC_W + 6)           // 45 rows after the row pass
 #define DESC_LD 40
 __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg,
-                                                     const int32_t* __restrict__ cnt, int cap,
-                                                     const float* __restrict__ kp_xy, const int32_t* __restrict__ kp_oct,
-                                                     const int32_t* __restrict__ kp_pos, float* __restrict__ kp_angle,
+                                                     const int32_t* __restrict__ fin_pos, const float* __restrict__ fin_resp,
+                                                     int32_t* __restrict__ cnt, int cap, float* __restrict__ kp_xy,
+                                                     float* __restrict__ kp_size, float* __restrict__ kp_resp,
+                                                     int32_t* __restrict__ kp_oct, float* __restrict__ kp_angle,
                                                      uint8_t* __restrict__ desc)
 {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int n = min(cnt[CNT_TOTAL], cap);
-    if (k >= n) return;
-    const int lvl = kp_oct[k];
+    // the levels' final lists are concatenated in level order: find this wave's keypoint
+    int lvl = 0, base = 0, total = 0;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        const int c = cnt[CNT_FIN + l];
+        if (k >= total + c) { lvl = l + 1; base = total + c; }
+        total += c;
+    }
+    if (k == 0 && lane == 0) cnt[CNT_TOTAL] = total;
+    if (k >= min(total, cap)) return;
     const LevelDev d = L->l[lvl];
-    const int w = d.w, pos = kp_pos[k];
+    const int w = d.w, pos = fin_pos[d.cand_off + (k - base)];
+    if (lane == 0) {
+        const int px = pos % w, py = pos / w;
+        kp_xy[2 * k] = (float)px * d.scale;
+        kp_xy[2 * k + 1] = (float)py * d.scale;
+        kp_size[k] = 31 * d.scale;
+        kp_resp[k] = fin_resp[d.cand_off + (k - base)];
+        kp_oct[k] = lvl;
+    }
     // intensity centroid over the circular patch: lanes 0..30 <-> u = lane-15
     const uint8_t* ctr = pimg + d.off + pos;
     int m10 = 0, m01 = 0;
@@ -564,7 +556,8 @@ __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev* __restric
     const float iscale = 1.f / d.scale;
     const float ar = angle * (float)(3.1415926535897932384626433832795 / 180.f);
     const float ca = (float)cos((double)ar), sa = (float)sin((double)ar);
-    const int cx = __float2int_rn(kp_xy[2 * k] * iscale), cy = __float2int_rn(kp_xy[2 * k + 1] * iscale);
+    // (centre exactly as OpenCV derives it: cvRound(kpt.pt * (1 / scale)) of the float32 point written above)
+    const int cx = __float2int_rn(((float)(pos % w) * d.scale) * iscale), cy = __float2int_rn(((float)(pos / w) * d.scale) * iscale);
     __shared__ uint16_t s_row[4][DESC_HR * DESC_LD];
     __shared__ uint8_t s_blur[4][DESC_W * DESC_LD];
     uint16_t* rowp = s_row[threadIdx.x >> 6];
@@ -641,9 +634,8 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
     const LevelsDev* dL = (const LevelsDev*)ctx->d_levels;
     const int with_mask = mask_mode != 0;
     StageTimer t(ctx, VO_T_ORB);
-    VO_HIP(ctx, hipMemsetAsync(ctx->orb.counters, 0, (CNT_HIST + NL * 256) * sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(k_orb_level0, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_img, img_stride, w, h, mask_mode,
-                       d_disp16, disp_stride, min_d16, max_d16, d_mask, mask_stride, ctx->orb.pyr_img, ctx->orb.pyr_mask);
+                       d_disp16, disp_stride, min_d16, max_d16, d_mask, mask_stride, ctx->orb.pyr_img, ctx->orb.pyr_mask, ctx->orb.counters);
     for (int l = 1; l < NL; l++)
         hipLaunchKernelGGL(k_orb_resize, dim3(div_up(Lh->l[l].w, 256), Lh->l[l].h), dim3(256), 0, ctx->stream, dL, l, ctx->rs_ofs,
                            ctx->rs_coef, ctx->orb.pyr_img, ctx->orb.pyr_mask, with_mask);
@@ -653,10 +645,9 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
     hipLaunchKernelGGL(k_orb_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.cand_pos, ctx->orb.cand_resp,
                        ctx->orb.candA_pos, ctx->orb.candA_resp, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.candB_pos,
                        ctx->orb.candB_resp, ctx->orb.counters);
-    hipLaunchKernelGGL(k_orb_pack, dim3(div_up(ctx->kp_cap, 256), NL), dim3(256), 0, ctx->stream, dL, ctx->orb.cand_pos, ctx->orb.cand_resp,
-                       ctx->orb.counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, ctx->orb.kp_pos);
-    hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img,
-                       ctx->orb.counters, ctx->kp_cap, fs->kp_xy, fs->kp_oct, ctx->orb.kp_pos, fs->kp_angle, fs->desc);
+    hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.cand_pos,
+                       ctx->orb.cand_resp, ctx->orb.counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, fs->kp_angle,
+                       fs->desc);
     VO_CHECK_LAUNCH(ctx);
     VO_HIP(ctx, hipMemcpyAsync(fs->n_kp_host, ctx->orb.counters + CNT_TOTAL, 4, hipMemcpyDeviceToHost, ctx->stream));
     return VO_OK;

@@ -96,9 +96,9 @@ static int orb_ws_alloc(vo_ctx* ctx, OrbWs& o)
     const size_t cand = (size_t)ctx->cand_cap * 4 * sizeof(int32_t);   // 8 levels together: < 3.2x level 0
     void** ps[] = { (void**)&o.pyr_img, (void**)&o.pyr_mask,
                     (void**)&o.cand_pos, (void**)&o.cand_resp, (void**)&o.candA_pos, (void**)&o.candA_resp, (void**)&o.candB_pos,
-                    (void**)&o.candB_resp, (void**)&o.kp_pos, (void**)&o.counters };
+                    (void**)&o.candB_resp, (void**)&o.counters };
     const size_t sz[] = { ctx->pyr_bytes, ctx->pyr_bytes, cand, cand, cand, cand, cand,
-                          cand, (size_t)ctx->kp_cap * 4, 8192 * 4 };
+                          cand, 8192 * 4 };
     for (size_t k = 0; k < sizeof(ps) / sizeof(ps[0]); k++)
         if (hipMalloc(ps[k], sz[k] + 256) != hipSuccess) return VO_E_HIP;
     return VO_OK;
@@ -107,7 +107,7 @@ static int orb_ws_alloc(vo_ctx* ctx, OrbWs& o)
 static void orb_ws_free(OrbWs& o)
 {
     void* ps[] = { o.pyr_img, o.pyr_mask, o.cand_pos, o.cand_resp, o.candA_pos, o.candA_resp,
-                   o.candB_pos, o.candB_resp, o.kp_pos, o.counters };
+                   o.candB_pos, o.candB_resp, o.counters };
     for (void* p : ps) if (p) (void)hipFree(p);
     o = OrbWs();
 }

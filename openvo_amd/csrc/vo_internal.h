@@ -52,7 +52,7 @@ struct FrameSlot {
 // scratch of one ORB run (pyramids, candidate lists, counters); one per look-ahead engine
 struct OrbWs {
     uint8_t *pyr_img = nullptr, *pyr_mask = nullptr;
-    int32_t *cand_pos = nullptr, *candA_pos = nullptr, *candB_pos = nullptr, *kp_pos = nullptr, *counters = nullptr;
+    int32_t *cand_pos = nullptr, *candA_pos = nullptr, *candB_pos = nullptr, *counters = nullptr;
     float *cand_resp = nullptr, *candA_resp = nullptr, *candB_resp = nullptr;
     hipEvent_t done = nullptr;   // end of the latest run in this workspace (any stream)
     bool done_valid = false;
