@@ -26,8 +26,8 @@
 //   k_sgbm_fin     records -> sub-pixel disp1 + disp2 candidates via atomicMin on (cost, scan order) keys
 //   k_sgbm_wta     unfused fallback (VO_FUSE_WTA=0, uniquenessRatio >= 100): per pixel (16 lanes) S = sat-sum
 //                  of all L volumes, same winner logic inline
-//   k_sgbm_lr      left-right consistency check
-//   k_median3, k_ccl_* : medianBlur(3) and filterSpeckles (run-based union-find labelling)
+//   k_lr_median3   left-right consistency check evaluated inside medianBlur(3)
+//   k_ccl_*        filterSpeckles (run-based union-find labelling)
 #include "vo_internal.h"
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -95,11 +95,12 @@ __device__ __forceinline__ void chan_bounds(const uint8_t* img, int W, int H, in
 }
 
 __global__ void k_sgbm_planes(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
-                              int ft, uint32_t* __restrict__ PL, uint32_t* __restrict__ PR)
+                              int ft, uint32_t* __restrict__ PL, uint32_t* __restrict__ PR, int* __restrict__ d2key)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
     size_t i = (size_t)y * W + x, plane = (size_t)W * H;
+    d2key[i] = D2_EMPTY;   // the disp2 candidates of this run start empty (saves a fill launch before the WTA)
     for (int c = 0; c < 2; c++) {
         int v, lo, hi;
         chan_bounds(L, W, H, x, y, c, ft, v, lo, hi);
@@ -731,11 +732,9 @@ __global__ void __launch_bounds__(256) k_sgbm_vwta(const int16_t* __restrict__ C
     }
 }
 
-// left-right check (per pixel) on the WTA results
-__global__ void k_sgbm_lr(const int16_t* __restrict__ disp1, const int* __restrict__ d2key, SgbmGeom g, int16_t* __restrict__ out)
+// left-right check of one pixel on the WTA results: disp1 or INVALID
+__device__ __forceinline__ int lr_value(const int16_t* __restrict__ disp1, const int* __restrict__ d2key, const SgbmGeom& g, int x, int y)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= g.W) return;
     const size_t rowo = (size_t)y * g.W;
     int d1 = g.invalid16;
     if (x >= g.minX1 && x < g.minX1 + g.W1) {
@@ -755,7 +754,7 @@ __global__ void k_sgbm_lr(const int16_t* __restrict__ disp1, const int* __restri
             if (bad) d1 = g.invalid16;
         }
     }
-    out[rowo + x] = (int16_t)d1;
+    return d1;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -763,15 +762,17 @@ __global__ void k_sgbm_lr(const int16_t* __restrict__ disp1, const int* __restri
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void cswap(int& a, int& b) { int t = min(a, b); b = max(a, b); a = t; }
 
-__global__ void k_median3(const int16_t* __restrict__ src, int W, int H, int16_t* __restrict__ dst)
+// left-right check + medianBlur(3) in one pass: the 9 checked values are evaluated in place (a few cached
+// loads each) instead of being written out by a launch of their own
+__global__ void k_lr_median3(const int16_t* __restrict__ disp1, const int* __restrict__ d2key, SgbmGeom g, int16_t* __restrict__ dst)
 {
+    const int W = g.W, H = g.H;
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
-    const int16_t* r0 = src + (size_t)max(y - 1, 0) * W;
-    const int16_t* r1 = src + (size_t)y * W;
-    const int16_t* r2 = src + (size_t)min(y + 1, H - 1) * W;
-    int xl = max(x - 1, 0), xr = min(x + 1, W - 1);
-    int p0 = r0[xl], p1 = r0[x], p2 = r0[xr], p3 = r1[xl], p4 = r1[x], p5 = r1[xr], p6 = r2[xl], p7 = r2[x], p8 = r2[xr];
+    const int y0 = max(y - 1, 0), y2 = min(y + 1, H - 1), xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+    int p0 = lr_value(disp1, d2key, g, xl, y0), p1 = lr_value(disp1, d2key, g, x, y0), p2 = lr_value(disp1, d2key, g, xr, y0);
+    int p3 = lr_value(disp1, d2key, g, xl, y), p4 = lr_value(disp1, d2key, g, x, y), p5 = lr_value(disp1, d2key, g, xr, y);
+    int p6 = lr_value(disp1, d2key, g, xl, y2), p7 = lr_value(disp1, d2key, g, x, y2), p8 = lr_value(disp1, d2key, g, xr, y2);
     cswap(p1, p2); cswap(p4, p5); cswap(p7, p8); cswap(p0, p1);
     cswap(p3, p4); cswap(p6, p7); cswap(p1, p2); cswap(p4, p5);
     cswap(p7, p8); cswap(p0, p3); cswap(p5, p8); cswap(p4, p7);
@@ -923,7 +924,7 @@ static PathPlan make_plan(const SgbmGeom& g, int mode)
 }
 
 template <int NP>
-static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, size_t vol, int16_t* d_disp_raw)
+static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, size_t vol)
 {
     // the last direction of the plan is the top-down vertical one: it runs fused with the WTA
     PathPlan plan = plan_all;
@@ -945,7 +946,6 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
     }
     {
         StageTimer t(ctx, VO_T_SGBM_WTA);
-        VO_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->ccl_size, D2_EMPTY, (size_t)g.W * g.H, ctx->stream));
         const size_t sh = (size_t)16 * g.Dp * sizeof(int16_t);   // one row of S per 16-lane group (the fused sweep keeps two)
         if (fuse) {
             const int nw = div_up(g.W1, 4);
@@ -962,7 +962,6 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
             hipLaunchKernelGGL((k_sgbm_wta<NP>), dim3((unsigned)((npix + 15) / 16)), dim3(256), sh, ctx->stream, ctx->S, vol, plan.n_dirs,
                                g, ctx->disp_tmp, ctx->ccl_size);
         }
-        hipLaunchKernelGGL(k_sgbm_lr, dim3(div_up(g.W, 256), g.H), dim3(256), 0, ctx->stream, ctx->disp_tmp, ctx->ccl_size, g, d_disp_raw);
         VO_CHECK_LAUNCH(ctx);
     }
     return VO_OK;
@@ -1019,7 +1018,7 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
     {
         StageTimer t(ctx, VO_T_SGBM_COST);
         hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
-                           ctx->planesL, ctx->planesR);
+                           ctx->planesL, ctx->planesR, ctx->ccl_size);
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
         const int TY = ctx->tune_sweep_ty;
         const int nw = bx / 64;
@@ -1041,19 +1040,19 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
     }
     int rc;
     switch (g.Dp / 32) {
-        case 1: rc = launch_agg<1>(ctx, g, plan, vol, ctx->disp_raw); break;
-        case 2: rc = launch_agg<2>(ctx, g, plan, vol, ctx->disp_raw); break;
-        case 3: rc = launch_agg<3>(ctx, g, plan, vol, ctx->disp_raw); break;
-        case 4: rc = launch_agg<4>(ctx, g, plan, vol, ctx->disp_raw); break;
-        case 5: rc = launch_agg<5>(ctx, g, plan, vol, ctx->disp_raw); break;
-        case 6: rc = launch_agg<6>(ctx, g, plan, vol, ctx->disp_raw); break;
-        case 7: rc = launch_agg<7>(ctx, g, plan, vol, ctx->disp_raw); break;
-        default: rc = launch_agg<8>(ctx, g, plan, vol, ctx->disp_raw); break;
+        case 1: rc = launch_agg<1>(ctx, g, plan, vol); break;
+        case 2: rc = launch_agg<2>(ctx, g, plan, vol); break;
+        case 3: rc = launch_agg<3>(ctx, g, plan, vol); break;
+        case 4: rc = launch_agg<4>(ctx, g, plan, vol); break;
+        case 5: rc = launch_agg<5>(ctx, g, plan, vol); break;
+        case 6: rc = launch_agg<6>(ctx, g, plan, vol); break;
+        case 7: rc = launch_agg<7>(ctx, g, plan, vol); break;
+        default: rc = launch_agg<8>(ctx, g, plan, vol); break;
     }
     if (rc) return rc;
     {
         StageTimer t(ctx, VO_T_SGBM_POST);
-        hipLaunchKernelGGL(k_median3, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, ctx->disp_raw, w, h, d_disp);
+        hipLaunchKernelGGL(k_lr_median3, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, ctx->disp_tmp, ctx->ccl_size, g, d_disp);
         if (e.speckleWindow > 0) {
             const int newVal = g.invalid16, maxDiff = 16 * e.speckleRange;
             hipLaunchKernelGGL(k_ccl_rows, dim3(h), dim3(256), 0, ctx->stream, d_disp, w, newVal, maxDiff, ctx->ccl_label, ctx->ccl_runlen, ctx->ccl_size);

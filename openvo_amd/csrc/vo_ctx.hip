@@ -157,7 +157,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->C, ctx->vol_cells);
     DALLOC(ctx->S, ctx->vol_cells * 5);   // one volume per MODE_SGBM path; grown to 8 for MODE_HH
     ctx->S_vols = 5;
-    DALLOC(ctx->disp_raw, npx); DALLOC(ctx->disp_tmp, npx); DALLOC(ctx->dump, 4096);
+    DALLOC(ctx->disp_tmp, npx); DALLOC(ctx->dump, 4096);
     DALLOC(ctx->ccl_label, npx); DALLOC(ctx->ccl_size, npx); DALLOC(ctx->ccl_runlen, npx);
     // ORB: 8-level pyramid is < 3.2x the base image
     ctx->pyr_bytes = npx * 4;
@@ -206,7 +206,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         if (f.ready) (void)hipEventDestroy(f.ready);
     }
     void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
-                   ctx->C, ctx->S, ctx->disp_raw, ctx->disp_tmp, ctx->dump, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
+                   ctx->C, ctx->S, ctx->disp_tmp, ctx->dump, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
                    ctx->m_idx, ctx->m_dist, ctx->pts_a, ctx->pts_b, ctx->st_a, ctx->st_b, ctx->xy_a, ctx->xy_b,
                    ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws, ctx->ransac_ws };
     for (void* p : ps) if (p) (void)hipFree(p);
@@ -219,7 +219,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     if (ctx->sgbm_done) (void)hipEventDestroy(ctx->sgbm_done);
     for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) {
         vo_ctx::SgbmWs& a = ctx->ws_alt[k];
-        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.disp_raw, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->la_stage[k] };
+        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->la_stage[k] };
         for (void* q : pa) if (q) (void)hipFree(q);
         if (a.done) (void)hipEventDestroy(a.done);
         orb_ws_free(a.orb);
@@ -443,7 +443,7 @@ static void engine_swap(vo_ctx* ctx, int engine)
     if (engine == 0) return;
     std::swap(ctx->planesL, a.planesL); std::swap(ctx->planesR, a.planesR);
     std::swap(ctx->C, a.C); std::swap(ctx->S, a.S); std::swap(ctx->S_vols, a.S_vols);
-    std::swap(ctx->disp_raw, a.disp_raw); std::swap(ctx->disp_tmp, a.disp_tmp);
+    std::swap(ctx->disp_tmp, a.disp_tmp);
     std::swap(ctx->ccl_runlen, a.ccl_runlen); std::swap(ctx->ccl_label, a.ccl_label); std::swap(ctx->ccl_size, a.ccl_size);
     std::swap(ctx->sgbm_done, a.done); std::swap(ctx->sgbm_done_valid, a.done_valid);
 }
@@ -464,7 +464,6 @@ static int engine_prepare(vo_ctx* ctx, int engine)
     VO_HIP(ctx, hipMalloc((void**)&a.C, ctx->vol_cells * 2 + 256));
     VO_HIP(ctx, hipMalloc((void**)&a.S, ctx->vol_cells * 2 * vols + 256));
     a.S_vols = vols;
-    VO_HIP(ctx, hipMalloc((void**)&a.disp_raw, npx * 2 + 256));
     VO_HIP(ctx, hipMalloc((void**)&a.disp_tmp, npx * 2 + 256));
     VO_HIP(ctx, hipMalloc((void**)&a.ccl_runlen, npx * 4 + 256));
     VO_HIP(ctx, hipMalloc((void**)&a.ccl_label, npx * 4 + 256));

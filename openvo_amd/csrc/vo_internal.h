@@ -71,7 +71,7 @@ struct vo_ctx {
     bool sgbm_done_valid = false;
     struct SgbmWs {
         uint32_t *planesL = nullptr, *planesR = nullptr;
-        int16_t *C = nullptr, *S = nullptr, *disp_raw = nullptr, *disp_tmp = nullptr;
+        int16_t *C = nullptr, *S = nullptr, *disp_tmp = nullptr;
         int32_t *ccl_runlen = nullptr, *ccl_label = nullptr, *ccl_size = nullptr;
         int S_vols = 0;
         hipEvent_t done = nullptr;
@@ -117,7 +117,6 @@ struct vo_ctx {
     int16_t* S = nullptr;          // aggregated volume
     size_t vol_cells = 0;
     int S_vols = 0;                // path volumes allocated behind S
-    int16_t* disp_raw = nullptr;
     int16_t* disp_tmp = nullptr;   // WTA output before the LR check
     int16_t* dump = nullptr;       // sink for the stores of lanes past the end of their scan line
     int32_t* ccl_runlen = nullptr;
