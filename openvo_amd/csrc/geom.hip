@@ -650,15 +650,6 @@ struct PoseOut {
     double T1[12], s1, T2[12], s2;
 };
 
-__global__ void k_points3d_dev(TapDisp tap, int cw, int ch, const float* __restrict__ xy, const int* __restrict__ n_dev,
-                               float* __restrict__ xyz, uint8_t* __restrict__ status, int* __restrict__ flags)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *n_dev) return;
-    bilinear_one(tap, cw, ch, xy[2 * i], xy[2 * i + 1], xyz + 3 * (size_t)i, status + i);
-    if (status[i] == 2) atomicOr(flags, 1);
-}
-
 // consistency matrix as bit rows: bits[i][w] bit b = | ||cur_i-cur_j|| - ||prev_i-prev_j|| | < thr, j = 64 w + b
 __global__ void k_pose_cons_bits(const float* __restrict__ prev, const float* __restrict__ cur, const int* __restrict__ m_dev,
                                  float thr, unsigned long long* __restrict__ bits, int words_cap, int* __restrict__ ncons)
@@ -700,13 +691,13 @@ __device__ __forceinline__ int wave_sum_i32_dpp(int v)
 
 // greedy clique on one wave over the bit matrix, then ordered compaction of the kept pairs.
 // 32-bit argmax keys ((value + m) << 16 | (0xFFFF - index)) need m < 32768.
-__global__ void __launch_bounds__(64) k_pose_clique(const unsigned long long* __restrict__ bits, int words_cap,
-                                                    const int* __restrict__ ncons, const int* __restrict__ m_dev, int use_filter,
-                                                    const float* __restrict__ pa, const float* __restrict__ pb,
-                                                    float* __restrict__ qa, float* __restrict__ qb, int* __restrict__ n1_out,
-                                                    int lds_m_cap, size_t lds_bits_cap)
+__device__ void pose_clique_wave(int* s_mem, const unsigned long long* __restrict__ bits, int words_cap,
+                                 const int* __restrict__ ncons, const int* __restrict__ m_dev, int use_filter,
+                                 const float* __restrict__ pa, const float* __restrict__ pb,
+                                 float* __restrict__ qa, float* __restrict__ qb, int* __restrict__ n1_out,
+                                 int lds_m_cap, size_t lds_bits_cap)
 {
-    extern __shared__ int s_mem[];   // 4 * lds_m_cap ints, then lds_bits_cap bytes for the bit matrix
+    // s_mem: 4 * lds_m_cap ints, then lds_bits_cap bytes for the bit matrix; called by ONE wave (threads 0..63)
     const int m = *m_dev;
     int* clique = s_mem;
     int* compat = s_mem + lds_m_cap;
@@ -978,9 +969,9 @@ __device__ void dev_umeyama_block(const float* __restrict__ src, const float* __
 
 // first fit + single-pass outlier rejection [reference :188-197] + final fit [:204], one block.
 // errs: scratch of capacity >= n1 doubles; qa/qb are compacted in place.
-__global__ void __launch_bounds__(1024) k_pose_fit(float* __restrict__ qa, float* __restrict__ qb, double outlier_thr, int min_matches,
-                                                   double* __restrict__ errs, float* __restrict__ ra, float* __restrict__ rb,
-                                                   PoseOut* __restrict__ out)
+__device__ void pose_fit_block(float* __restrict__ qa, float* __restrict__ qb, double outlier_thr, int min_matches,
+                               double* __restrict__ errs, float* __restrict__ ra, float* __restrict__ rb,
+                               PoseOut* __restrict__ out)
 {
     __shared__ double sh[10][16];
     __shared__ double s_T[12], s_scale, s_med;
@@ -1055,12 +1046,75 @@ __global__ void __launch_bounds__(1024) k_pose_fit(float* __restrict__ qa, float
         out->rc2 = 1;
 }
 
-__global__ void k_pose_init(PoseOut* out, const int* __restrict__ m_dev, int* __restrict__ flags_dev)
+// First half of the fused pose step in ONE block (was five launches): wave 0 runs the ratio test with ordered
+// compaction, then the whole block looks up the matched keypoints' 3-D positions in both frames and clears the
+// consistency counters.  A short chain of launches is what the step costs under load, not its arithmetic.
+__global__ void __launch_bounds__(256) k_pose_prep(const int32_t* __restrict__ idx, const int32_t* __restrict__ dist, int nq, double ratio,
+                                                   const float* __restrict__ xy_q, const float* __restrict__ xy_t,
+                                                   int32_t* __restrict__ q_out, int32_t* __restrict__ t_out, float* __restrict__ xyq_out,
+                                                   float* __restrict__ xyt_out, int32_t* __restrict__ m_out, PoseOut* __restrict__ out,
+                                                   int* __restrict__ flags_dev, TapDisp ta, TapDisp tb, int cw, int ch,
+                                                   float* __restrict__ pts_a, float* __restrict__ pts_b, uint8_t* __restrict__ st_a,
+                                                   uint8_t* __restrict__ st_b, int* __restrict__ ncons)
 {
-    out->M = *m_dev; out->n1 = 0; out->n2 = 0; out->flags = 0; out->rc1 = 1; out->rc2 = 1;
-    *flags_dev = 0;
+    __shared__ int s_m;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int base = 0;
+        for (int i0 = 0; i0 < nq; i0 += 64) {
+            int i = i0 + lane;
+            bool keep = false;
+            int t = -1;
+            if (i < nq) {
+                t = idx[2 * i];
+                double a = (double)(float)dist[2 * i], b = (double)(float)dist[2 * i + 1];
+                keep = idx[2 * i + 1] >= 0 && a < ratio * b;
+            }
+            unsigned long long bal = __ballot(keep);
+            if (keep) {
+                int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                q_out[pos] = i; t_out[pos] = t;
+                xyq_out[2 * pos] = xy_q[2 * i]; xyq_out[2 * pos + 1] = xy_q[2 * i + 1];
+                xyt_out[2 * pos] = xy_t[2 * t]; xyt_out[2 * pos + 1] = xy_t[2 * t + 1];
+            }
+            base += __popcll(bal);
+        }
+        if (lane == 0) {
+            s_m = base;
+            *m_out = base;
+            out->M = base; out->n1 = 0; out->n2 = 0; out->flags = 0; out->rc1 = 1; out->rc2 = 1;
+            *flags_dev = 0;
+        }
+    }
+    __syncthreads();
+    const int m = s_m;
+    int bad = 0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        bilinear_one(ta, cw, ch, xyq_out[2 * i], xyq_out[2 * i + 1], pts_a + 3 * (size_t)i, st_a + i);
+        bilinear_one(tb, cw, ch, xyt_out[2 * i], xyt_out[2 * i + 1], pts_b + 3 * (size_t)i, st_b + i);
+        bad |= st_a[i] == 2 || st_b[i] == 2;
+    }
+    if (bad) atomicOr(flags_dev, 1);
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) ncons[i] = 0;
 }
-__global__ void k_pose_flags(PoseOut* out, const int* __restrict__ flags_dev) { out->flags |= *flags_dev; }
+
+// Second half in ONE block (was three launches): wave 0 picks the rigid clique, then all 1024 threads run the
+// first fit, the outlier pass and the final fit.
+__global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* __restrict__ bits, int words_cap,
+                                                     const int* __restrict__ ncons, const int* __restrict__ m_dev, int use_filter,
+                                                     const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ qa,
+                                                     float* __restrict__ qb, int lds_m_cap, size_t lds_bits_cap,
+                                                     const int* __restrict__ flags_dev, double outlier_thr, int min_matches,
+                                                     double* __restrict__ errs, float* __restrict__ ra, float* __restrict__ rb,
+                                                     PoseOut* __restrict__ out)
+{
+    extern __shared__ int s_mem[];
+    if (threadIdx.x < 64)
+        pose_clique_wave(s_mem, bits, words_cap, ncons, m_dev, use_filter, pa, pb, qa, qb, &out->n1, lds_m_cap, lds_bits_cap);
+    if (threadIdx.x == 0) out->flags |= *flags_dev;
+    __syncthreads();
+    pose_fit_block(qa, qb, outlier_thr, min_matches, errs, ra, rb, out);
+}
 
 // enqueue the whole fused step for two slots on ctx->stream with the scratch currently installed in ctx; the
 // PoseOut record is copied to host_out (pinned) at the end.  No host synchronisation.
@@ -1087,39 +1141,33 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
     float* d_qb = (float*)wsp; wsp += (size_t)nq * 12;
     float* d_ra = (float*)wsp; wsp += (size_t)nq * 12;
     float* d_rb = (float*)wsp;
-    int* d_m = ctx->m_count;  // k_ratio_compact writes M here
+    int* d_m = ctx->m_count;  // k_pose_prep writes the match count M here
     int rc;
     {
         StageTimer t(ctx, VO_T_MATCH);
         rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->m_idx, ctx->m_dist);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(64), 0, ctx->stream, ctx->m_idx, ctx->m_dist, a.n_kp, ratio, a.kp_xy,
-                           b.kp_xy, ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, d_m);
-        VO_CHECK_LAUNCH(ctx);
     }
     {
         StageTimer t(ctx, VO_T_POSE);
-        hipLaunchKernelGGL(k_pose_init, dim3(1), dim3(1), 0, ctx->stream, d_out, d_m, d_flags);
         int x0 = 0, y0 = 0, x1 = a.w, y1 = a.h;
         if (ctx->has_roi) { x0 = ctx->roi[0]; y0 = ctx->roi[1]; x1 = ctx->roi[2] < a.w ? ctx->roi[2] : a.w; y1 = ctx->roi[3] < a.h ? ctx->roi[3] : a.h; }
         TapDisp ta{ a.disp16, a.w, x0, y0, make_q(ctx->Q) };
         TapDisp tb{ b.disp16, b.w, x0, y0, make_q(ctx->Q) };
-        hipLaunchKernelGGL(k_points3d_dev, dim3(div_up(nq, 64)), dim3(64), 0, ctx->stream, ta, x1 - x0, y1 - y0, ctx->xy_a, d_m, ctx->pts_a, ctx->st_a, d_flags);
-        hipLaunchKernelGGL(k_points3d_dev, dim3(div_up(nq, 64)), dim3(64), 0, ctx->stream, tb, x1 - x0, y1 - y0, ctx->xy_b, d_m, ctx->pts_b, ctx->st_b, d_flags);
+        hipLaunchKernelGGL(k_pose_prep, dim3(1), dim3(256), 0, ctx->stream, ctx->m_idx, ctx->m_dist, a.n_kp, ratio, a.kp_xy, b.kp_xy,
+                           ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, d_m, d_out, d_flags, ta, tb, x1 - x0, y1 - y0, ctx->pts_a,
+                           ctx->pts_b, ctx->st_a, ctx->st_b, d_ncons);
         const int use_filter = rigidity_thr > 0;
-        if (use_filter) {
-            VO_HIP(ctx, hipMemsetAsync(d_ncons, 0, (size_t)nq * 4, ctx->stream));
+        if (use_filter)
             hipLaunchKernelGGL(k_pose_cons_bits, dim3(words, nq), dim3(64), 0, ctx->stream, ctx->pts_a, ctx->pts_b, d_m, (float)rigidity_thr,
                                d_bits, words, d_ncons);
-        }
-        // LDS: 3 int arrays of nq (rounded to even so the bit matrix stays 8-byte aligned) + bit matrix if <= 48 KB
+        // LDS: 4 int arrays of nq (rounded to even so the bit matrix stays 8-byte aligned) + bit matrix if <= 48 KB
         const int m_cap = (nq + 1) & ~1;
         size_t bits_cap = (size_t)nq * words * 8;
         if ((size_t)m_cap * 16 + bits_cap > 60 * 1024) bits_cap = 0;
-        hipLaunchKernelGGL(k_pose_clique, dim3(1), dim3(64), (size_t)m_cap * 16 + bits_cap, ctx->stream, d_bits, words, d_ncons, d_m,
-                           use_filter, ctx->pts_a, ctx->pts_b, d_qa, d_qb, &d_out->n1, m_cap, bits_cap);
-        hipLaunchKernelGGL(k_pose_flags, dim3(1), dim3(1), 0, ctx->stream, d_out, d_flags);
-        hipLaunchKernelGGL(k_pose_fit, dim3(1), dim3(1024), 0, ctx->stream, d_qa, d_qb, outlier_thr, min_matches, d_errs, d_ra, d_rb, d_out);
+        hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(1024), (size_t)m_cap * 16 + bits_cap, ctx->stream, d_bits, words, d_ncons, d_m,
+                           use_filter, ctx->pts_a, ctx->pts_b, d_qa, d_qb, m_cap, bits_cap, d_flags, outlier_thr, min_matches, d_errs,
+                           d_ra, d_rb, d_out);
         VO_CHECK_LAUNCH(ctx);
         VO_HIP(ctx, hipMemcpyAsync(host_out, d_out, sizeof(PoseOut), hipMemcpyDeviceToHost, ctx->stream));
     }
