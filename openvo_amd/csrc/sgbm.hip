@@ -856,7 +856,14 @@ __global__ void __launch_bounds__(256) k_ccl_rows(const int16_t* __restrict__ im
     }
 }
 
-__global__ void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int* __restrict__ L)
+// Only "is the component larger than maxSize" is ever asked, so runs that are longer than maxSize by
+// themselves ("big") never enter the union-find: big-big contacts are ignored (both survive anyway) and a
+// small run touching a big one is only flagged (RUN_TOUCH in its runlen word; k_ccl_sizes then credits its
+// component with maxSize + 1).  The wide regions of a disparity map -- whose unions all fought over the same
+// few roots -- drop out; the union-find is left with the small runs.
+#define RUN_TOUCH (1 << 30)
+__global__ void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int maxSize, int* __restrict__ L,
+                             int* __restrict__ runlen)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W || y + 1 >= H) return;
@@ -864,10 +871,23 @@ __global__ void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int 
     const int v = img[i], u = img[i + W];
     if (v == newVal || u == newVal || abs(v - u) > maxDiff) return;
     const int a = L[i], b = L[i + W];
+    bool head_a = x == 0, head_b = x == 0, joined_left = false;
     if (x > 0) {
-        // the same pair of runs was already joined by the column to the left
         const int v1 = img[i - 1], u1 = img[i + W - 1];
-        if (v1 != newVal && u1 != newVal && abs(v1 - u1) <= maxDiff && L[i - 1] == a && L[i + W - 1] == b) return;
+        head_a = v1 == newVal || abs(v - v1) > maxDiff;
+        head_b = u1 == newVal || abs(u - u1) > maxDiff;
+        joined_left = v1 != newVal && u1 != newVal && abs(v1 - u1) <= maxDiff && !head_a && !head_b;   // same two runs, one column earlier
+    }
+    if (joined_left) return;
+    // a head pixel's label may already point at an ancestor: its own index is the run head
+    const int ha = head_a ? i : a, hb = head_b ? i + W : b;
+    const int la = ((volatile int*)runlen)[ha], lb = ((volatile int*)runlen)[hb];
+    const bool big_a = (la & ~RUN_TOUCH) > maxSize, big_b = (lb & ~RUN_TOUCH) > maxSize;
+    if (big_a && big_b) return;
+    if (big_a != big_b) {
+        const int hs = big_a ? hb : ha, ls = big_a ? lb : la;
+        if (!(ls & RUN_TOUCH)) atomicOr(&runlen[hs], RUN_TOUCH);
+        return;
     }
     uf_union(L, a, b);
 }
@@ -889,7 +909,8 @@ __global__ void k_ccl_sizes(const int16_t* __restrict__ img, int W, int H, int n
     // only "size <= maxSize" is ever asked, and the counter only grows: once it is past the limit
     // further adds are pointless (this removes the contention on the few huge components)
     if (((volatile int*)size)[root] > maxSize) return;
-    atomicAdd(&size[root], runlen[i]);
+    const int len = runlen[i];
+    atomicAdd(&size[root], (len & ~RUN_TOUCH) + ((len & RUN_TOUCH) ? maxSize + 1 : 0));
 }
 
 __global__ void k_ccl_apply(int16_t* __restrict__ img, int n, int newVal, int maxSize, const int* __restrict__ L,
@@ -1056,7 +1077,7 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
         if (e.speckleWindow > 0) {
             const int newVal = g.invalid16, maxDiff = 16 * e.speckleRange;
             hipLaunchKernelGGL(k_ccl_rows, dim3(h), dim3(256), 0, ctx->stream, d_disp, w, newVal, maxDiff, ctx->ccl_label, ctx->ccl_runlen, ctx->ccl_size);
-            hipLaunchKernelGGL(k_ccl_vmerge, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, ctx->ccl_label);
+            hipLaunchKernelGGL(k_ccl_vmerge, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ccl_label, ctx->ccl_runlen);
             hipLaunchKernelGGL(k_ccl_sizes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ccl_label, ctx->ccl_runlen, ctx->ccl_size);
             hipLaunchKernelGGL(k_ccl_apply, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_disp, n, newVal, e.speckleWindow, ctx->ccl_label, ctx->ccl_size);
         }
