@@ -85,10 +85,12 @@ def _get_rectangles(K, dist, R, P, img_size):
     gx, gy = np.meshgrid(np.arange(N) * (w - 1) / (N - 1), np.arange(N) * (h - 1) / (N - 1))
     grid = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
     p = undistort_points(grid, K, dist, R, P).astype(np.float32).astype(np.float64).reshape(N, N, 2)
-    ix0, ix1 = p[:, 0, 0].max(), p[:, N - 1, 0].min()
-    iy0, iy1 = p[0, :, 1].max(), p[N - 1, :, 1].min()
-    inner = (ix0, iy0, ix1 - ix0, iy1 - iy0)
-    outer = (p[..., 0].min(), p[..., 1].min(), p[..., 0].max() - p[..., 0].min(), p[..., 1].max() - p[..., 1].min())
+    p32 = p.astype(np.float32)       # cv::Rect_<float>: extents are float32 differences
+    ix0, ix1 = p32[:, 0, 0].max(), p32[:, N - 1, 0].min()
+    iy0, iy1 = p32[0, :, 1].max(), p32[N - 1, :, 1].min()
+    inner = (float(ix0), float(iy0), float(np.float32(ix1 - ix0)), float(np.float32(iy1 - iy0)))
+    ox0, ox1, oy0, oy1 = p32[..., 0].min(), p32[..., 0].max(), p32[..., 1].min(), p32[..., 1].max()
+    outer = (float(ox0), float(oy0), float(np.float32(ox1 - ox0)), float(np.float32(oy1 - oy0)))
     return inner, outer
 
 
@@ -115,20 +117,19 @@ def stereo_rectify(K1, D1, K2, D2, img_size, R, T):
     R1 = wR @ r_r.T
     R2 = wR @ r_r
     t = R2 @ T
-    fc_new = np.inf
-    for K, D in ((K1, D1), (K2, D2)):
-        k1 = _dist14(D)[0]
-        fc = K[idx ^ 1, idx ^ 1]
-        if k1 < 0:
-            fc *= 1 + k1 * (nx * nx + ny * ny) / (4 * fc * fc)
-        fc_new = min(fc_new, fc)
+    # OpenCV >= 3.4.8 / 4.1.2 (the reference needs >= 4.5.5 for estimateAffine3D(force_rotation)):
+    # fc_new = (K1[idx^1, idx^1] + K2[idx^1, idx^1]) * ratio, ratio = newImageSize / imageSize / 2 = 0.5
+    # when newImageSize is left at its default; no k1-dependent shrink (that rule is pre-3.4.8)
+    fc_new = (K1[idx ^ 1, idx ^ 1] + K2[idx ^ 1, idx ^ 1]) * 0.5
     cc = []
-    corners = np.array([[0, 0], [nx - 1, 0], [0, ny - 1], [nx - 1, ny - 1]], np.float64)
+    # cvStereoRectify keeps the four corners in CvPoint2D32f: undistorted points, their homogeneous
+    # form and the projected points are float32; the average is taken in double
+    corners = np.array([[0, 0], [nx - 1, 0], [0, ny - 1], [nx - 1, ny - 1]], np.float32)
     for K, D, Rk in ((K1, D1, R1), (K2, D2, R2)):
-        n = undistort_points(corners, K, D)
+        n = undistort_points(corners, K, D).astype(np.float32).astype(np.float64)
         X = np.stack([n[:, 0], n[:, 1], np.ones(4)], 1) @ Rk.T
-        proj = np.stack([fc_new * X[:, 0] / X[:, 2], fc_new * X[:, 1] / X[:, 2]], 1)
-        avg = proj.mean(0)
+        proj = np.stack([fc_new * X[:, 0] / X[:, 2], fc_new * X[:, 1] / X[:, 2]], 1).astype(np.float32)
+        avg = proj.astype(np.float64).mean(0)
         cc.append(np.array([(nx - 1) / 2 - avg[0], (ny - 1) / 2 - avg[1]]))
     # CALIB_ZERO_DISPARITY: both principal points become their average
     cc[0] = cc[1] = (cc[0] + cc[1]) * 0.5

@@ -198,21 +198,89 @@ class DeviceImage:
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()
-        return a if dtype is None else a.astype(dtype)
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    # The reference hands out numpy views (stereo_camera.py:53-55); user code written against it may do
+    # anything an ndarray allows.  Everything below materialises the image (one download, cached) and
+    # delegates: ufuncs and numpy functions called on the object, operators, and any ndarray attribute
+    # or method (.astype, .reshape, .max(), .copy(), .T, .flags, ...).
+    __array_priority__ = 100.0
+
+    @staticmethod
+    def _unwrap(x):
+        if isinstance(x, DeviceImage):
+            return x.numpy()
+        if isinstance(x, (tuple, list)) and any(isinstance(v, DeviceImage) for v in x):
+            return type(x)(DeviceImage._unwrap(v) for v in x)
+        return x
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if "out" in kwargs:
+            if any(isinstance(o, DeviceImage) for o in kwargs["out"]):
+                raise TypeError("a DeviceImage is read-only: it cannot be the out= target of a ufunc")
+        return getattr(ufunc, method)(*[self._unwrap(x) for x in inputs], **kwargs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        return func(*[self._unwrap(a) for a in args], **{k: self._unwrap(v) for k, v in kwargs.items()})
+
+    def __getattr__(self, name):
+        # only reached for names the class does not define: forward to the materialised array
+        if name.startswith("__") or name in ("frame", "kind"):
+            raise AttributeError(name)
+        return getattr(self.numpy(), name)
 
     def __getitem__(self, idx):
         return self.numpy()[idx]
 
+    def __setitem__(self, idx, value):
+        raise TypeError("a DeviceImage is read-only; use np.array(img) for a writable copy")
+
     def __len__(self):
         return self.shape[0]
 
-    # comparisons / arithmetic used by the reference's feature_mask on a plain array
-    def __ge__(self, o): return self.numpy() >= o
-    def __le__(self, o): return self.numpy() <= o
-    def __gt__(self, o): return self.numpy() > o
-    def __lt__(self, o): return self.numpy() < o
-    def __mul__(self, o): return self.numpy() * o
-    def __truediv__(self, o): return self.numpy() / o
+    def __iter__(self):
+        return iter(self.numpy())
+
+    def __contains__(self, v):
+        return v in self.numpy()
+
+    def __repr__(self):
+        return "DeviceImage(%s, shape=%s, dtype=%s)" % (self.kind, self.shape, self.dtype)
+
+    def __bool__(self):
+        return bool(self.numpy())
+
+    def __float__(self):
+        return float(self.numpy())
+
+    def __int__(self):
+        return int(self.numpy())
+
+    def __copy__(self):
+        return self.numpy().copy()
+
+    def __deepcopy__(self, memo):
+        return self.numpy().copy()
+
+
+def _forward_operators():
+    import operator as op
+    binary = ("add", "sub", "mul", "truediv", "floordiv", "mod", "pow", "matmul", "and", "or", "xor", "lshift", "rshift")
+    for name in binary:
+        f = getattr(op, name + "_" if name in ("and", "or") else name)
+        setattr(DeviceImage, "__%s__" % name, (lambda f: lambda self, o: f(self.numpy(), DeviceImage._unwrap(o)))(f))
+        setattr(DeviceImage, "__r%s__" % name, (lambda f: lambda self, o: f(DeviceImage._unwrap(o), self.numpy()))(f))
+    for name in ("lt", "le", "gt", "ge", "eq", "ne"):
+        f = getattr(op, name)
+        setattr(DeviceImage, "__%s__" % name, (lambda f: lambda self, o: f(self.numpy(), DeviceImage._unwrap(o)))(f))
+    for name, f in (("neg", op.neg), ("pos", op.pos), ("abs", abs), ("invert", op.invert)):
+        setattr(DeviceImage, "__%s__" % name, (lambda f: lambda self: f(self.numpy()))(f))
+    DeviceImage.__hash__ = None       # like ndarray: == is elementwise, so instances are unhashable
+
+
+_forward_operators()
 
 
 class DisparityMask(DeviceImage):

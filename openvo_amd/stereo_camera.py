@@ -36,6 +36,33 @@ def _RESERVED():
     return _RESERVED
 
 
+def _load_plain(path):
+    path = os.fspath(path)
+    if path.lower().endswith(".json"):
+        import json
+        with open(path, "r") as fh:
+            d = json.load(fh)
+        if not isinstance(d, dict):
+            raise ValueError("%s: expected a JSON object" % path)
+        return d
+    if path.lower().endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    raise ValueError("%s: expected a .json or .npz file (use from_pfiles for the reference's pickles)" % path)
+
+
+def _save_plain(path, d):
+    path = os.fspath(path)
+    if path.lower().endswith(".json"):
+        import json
+        with open(path, "w") as fh:
+            json.dump({k: (np.asarray(v).tolist() if not isinstance(v, (int, float)) else v) for k, v in d.items()}, fh)
+    elif path.lower().endswith(".npz"):
+        np.savez(path, **{k: np.asarray(v) for k, v in d.items()})
+    else:
+        raise ValueError("%s: expected a .json or .npz file" % path)
+
+
 class StereoCamera:
     @classmethod
     def from_pfiles(cls, left_cam_file, right_cam_file, rect_file, sgbm_file, img_size, **kw):
@@ -48,6 +75,35 @@ class StereoCamera:
                 loaded.append(pickle.load(fh))
         cam_l, cam_r, rect, sgbm = loaded
         return cls(cam_l["K"], cam_l["dist"], cam_r["K"], cam_r["dist"], rect, sgbm, img_size, **kw)
+
+    SGBM_KEYS = ("minDisparity", "numDisparities", "blockSize", "P1", "P2", "disp12MaxDiff", "preFilterCap",
+                 "uniquenessRatio", "speckleWindowSize", "speckleRange")
+
+    @classmethod
+    def from_files(cls, left_cam_file, right_cam_file, rect_file, sgbm_file, img_size, **kw):
+        """The same four dicts as from_pfiles from files that cannot execute code: each file is a .json
+        object or an .npz archive (loaded with allow_pickle=False) holding the reference's keys -- cameras
+        'K' (3x3) and 'dist', rectification 'R' (3x3 or rotation vector) and 'T', and the ten StereoSGBM
+        integers.  Not in the reference (a safe alternative to pickle)."""
+        cam_l, cam_r, rect, sgbm = (_load_plain(f) for f in (left_cam_file, right_cam_file, rect_file, sgbm_file))
+        for name, d, keys in (("left camera", cam_l, ("K", "dist")), ("right camera", cam_r, ("K", "dist")),
+                              ("rectification", rect, ("R", "T")), ("sgbm", sgbm, cls.SGBM_KEYS)):
+            missing = [k for k in keys if k not in d]
+            if missing:
+                raise KeyError("%s file lacks %s" % (name, missing))
+        sgbm = {k: int(np.asarray(sgbm[k]).reshape(-1)[0]) for k in cls.SGBM_KEYS}
+        return cls(np.asarray(cam_l["K"], np.float64), np.asarray(cam_l["dist"], np.float64),
+                   np.asarray(cam_r["K"], np.float64), np.asarray(cam_r["dist"], np.float64),
+                   {"R": np.asarray(rect["R"], np.float64), "T": np.asarray(rect["T"], np.float64)}, sgbm, img_size, **kw)
+
+    @staticmethod
+    def save_files(left_cam_file, right_cam_file, rect_file, sgbm_file, K_left, dist_left, K_right, dist_right,
+                   rect_params, sgbm_params):
+        """Write the four calibration files from_files reads (.json or .npz by extension)."""
+        _save_plain(left_cam_file, {"K": K_left, "dist": dist_left})
+        _save_plain(right_cam_file, {"K": K_right, "dist": dist_right})
+        _save_plain(rect_file, {"R": rect_params["R"], "T": rect_params["T"]})
+        _save_plain(sgbm_file, {k: int(sgbm_params[k]) for k in StereoCamera.SGBM_KEYS})
 
     def __init__(self, K_left, dist_left, K_right, dist_right, rect_params, sgbm_params, img_size,
                  device=0, max_keypoints=2000, context=None):
@@ -74,7 +130,7 @@ class StereoCamera:
         self._slot_owner = [None] * _native.VO_NUM_SLOTS   # weak bookkeeping: FrameHandle per slot
         self._slot_gen = [0] * _native.VO_NUM_SLOTS        # bumped whenever a slot receives a new pair
         self._next_slot = 0
-        # staged pairs: how many following pairs run their SGBM ahead (0..4; env VO_LOOKAHEAD overrides)
+        # staged pairs: how many following pairs run their SGBM ahead (default 7, at most VO_NUM_SLOTS - 3; env VO_LOOKAHEAD overrides)
         self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "7"))
         self._lookahead = []         # [((index, preprocessed), slot, (w, h))] of the pairs in flight
         self._n_staged = 0
