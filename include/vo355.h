@@ -210,6 +210,9 @@ int vo_get_timings(vo_ctx* ctx, double* ms_out /*VO_T_NSTAGES*/, int64_t* launch
  * directions aggregated inside its k_sgbm_paths launch (the remaining top-down vertical direction
  * runs fused with the WTA) */
 int vo_sgbm_last_geometry(vo_ctx* ctx, int64_t* cells, int* n_paths);
+/* health of the raster aggregation sweeps (synchronises): *error_out != 0 when a wait between rows / bands
+ * ever exceeded its poll limit (the affected disparities are then undefined); sticky until vo_destroy */
+int vo_sgbm_raster_status(vo_ctx* ctx, int* error_out);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ SYMBOLS = [
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints", "vo_download_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
-    "vo_sgbm_last_geometry",
+    "vo_sgbm_last_geometry", "vo_sgbm_raster_status",
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
         L.vo_enable_timing.argtypes = [vp, ci]
         L.vo_get_timings.argtypes = [vp, vp, vp, ci]
         L.vo_sgbm_last_geometry.argtypes = [vp, vp, vp]
+        L.vo_sgbm_raster_status.argtypes = [vp, vp]
         _lib = L
     return _lib
 
@@ -461,6 +462,12 @@ class Context:
         n = np.zeros(len(T_STAGES), np.int64)
         self._ck(self._lib.vo_get_timings(self._h, _p(ms), _p(n), int(reset)))
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(T_STAGES)}
+
+    def sgbm_raster_status(self):
+        """0 = every raster sweep so far completed its hand-offs; non-zero = a wait timed out (sticky)."""
+        e = ctypes.c_int(0)
+        self._ck(self._lib.vo_sgbm_raster_status(self._h, ctypes.byref(e)))
+        return e.value
 
     def sgbm_last_geometry(self):
         cells, paths = ctypes.c_int64(0), ctypes.c_int(0)

@@ -95,9 +95,15 @@ __device__ __forceinline__ void chan_bounds(const uint8_t* img, int W, int H, in
 }
 
 __global__ void k_sgbm_planes(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
-                              int ft, uint32_t* __restrict__ PL, uint32_t* __restrict__ PR, int* __restrict__ d2key)
+                              int ft, uint32_t* __restrict__ PL, uint32_t* __restrict__ PR, int* __restrict__ d2key,
+                              int* __restrict__ rs_ctl, int rs_ctl_words)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    // the raster sweeps' band tickets and progress counters of this run start at zero (word 1 of each of the
+    // two control blocks is its sticky error flag and is left alone)
+    if (y == 0 && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < rs_ctl_words; i += blockDim.x)
+            if ((i % (rs_ctl_words / 2)) != 1) rs_ctl[i] = 0;
     if (x >= W) return;
     size_t i = (size_t)y * W + x, plane = (size_t)W * H;
     d2key[i] = D2_EMPTY;   // the disp2 candidates of this run start empty (saves a fill launch before the WTA)
@@ -732,6 +738,8 @@ __global__ void __launch_bounds__(256) k_sgbm_vwta(const int16_t* __restrict__ C
     }
 }
 
+#include "sgbm_raster.inc"
+
 // left-right check of one pixel on the WTA results: disp1 or INVALID
 __device__ __forceinline__ int lr_value(const int16_t* __restrict__ disp1, const int* __restrict__ d2key, const SgbmGeom& g, int x, int y)
 {
@@ -944,12 +952,75 @@ static PathPlan make_plan(const SgbmGeom& g, int mode)
     return p;
 }
 
+// rows per band (= compute waves per workgroup) of the raster sweep: two waves per SIMD while the ring fits in LDS
+static inline int raster_rows(int NP) { return NP <= 4 ? 8 : 4; }
+
+template <int NP, bool PAD, bool REV, bool HASIN, bool WTA>
+static int launch_raster(vo_ctx* ctx, const SgbmGeom& g, const int16_t* Lin, int16_t* Sout, int* ctl)
+{
+    const int R = raster_rows(NP), nbands = div_up(g.H, R);
+    const size_t lds = (size_t)(R + 1) * RS_RING * NP * 256 + (size_t)(R + 1) * RS_RING * 16 + (size_t)(16 + ((R + 3) & ~3)) * 4 +
+                       (size_t)R * 2 * 4 * g.Dp * 2;
+    auto kern = k_sgbm_raster<NP, PAD, REV, HASIN, WTA>;
+    static bool attr_set = false;     // per instantiation: allow more than 64 KB of dynamic LDS
+    if (!attr_set) {
+        VO_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nbands), dim3((R + 2) * 64), lds, ctx->stream, ctx->C, Lin, Sout, ctx->rs_bnd, ctl, g, R, nbands,
+                       ctx->ccl_label, ctx->ccl_runlen, ctx->dump);
+    VO_CHECK_LAUNCH(ctx);
+    return VO_OK;
+}
+
 template <int NP>
 static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, size_t vol)
 {
     // the last direction of the plan is the top-down vertical one: it runs fused with the WTA
     PathPlan plan = plan_all;
     const bool fuse = ctx->tune_fuse_wta != 0 && g.ur < 100;   // the fused sweep only carries the threshold form of the uniqueness test
+    if (fuse && ctx->tune_raster) {
+        // raster scheme: MODE_SGBM = E by the line kernel, then W/NW/N/NE + WTA in one raster pass;
+        // MODE_HH = E/SE/S/SW in a reverse raster pass (sum stored), then W/NW/N/NE + WTA in the forward pass
+        int* ctlA = ctx->rs_ctl;
+        int* ctlB = ctx->rs_ctl + ctx->rs_ctl_words / 2;
+        int rc;
+        {
+            StageTimer t(ctx, VO_T_SGBM_AGG);
+            if (plan_all.n_dirs == 5) {
+                PathPlan pe = plan_all;
+                pe.n_dirs = 1;
+                pe.sx[0] = -1; pe.sy[0] = 0; pe.nlines[0] = g.H;
+                pe.first_wave[0] = 0;
+                for (int k = 0; k < VO_MAX_DIRS; k++) pe.first_wave[k + 1] = div_up(g.H, 4);
+                const int nwaves = pe.first_wave[1];
+                if (NP <= 4)
+                    hipLaunchKernelGGL((k_sgbm_paths<NP, 8>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, pe, ctx->dump);
+                else
+                    hipLaunchKernelGGL((k_sgbm_paths<NP, 4>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, pe, ctx->dump);
+                VO_CHECK_LAUNCH(ctx);
+            } else {
+                if ((rc = launch_raster<NP, false, true, false, false>(ctx, g, nullptr, ctx->S, ctlA))) return rc;
+            }
+        }
+        {
+            StageTimer t(ctx, VO_T_SGBM_WTA);
+            if (g.D == g.Dp) rc = launch_raster<NP, false, false, true, true>(ctx, g, ctx->S, nullptr, ctlB);
+            else rc = launch_raster<NP, true, false, true, true>(ctx, g, ctx->S, nullptr, ctlB);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
+            VO_CHECK_LAUNCH(ctx);
+        }
+        ctx->last_paths = plan_all.n_dirs == 5 ? 1 : 0;
+        return VO_OK;
+    }
+    if (plan_all.n_dirs > ctx->S_vols) {
+        // the line-per-direction scheme stores one volume per direction; grow once
+        if (ctx->S) (void)hipFree(ctx->S);
+        ctx->S = nullptr; ctx->S_vols = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->S, ctx->vol_cells * sizeof(int16_t) * plan_all.n_dirs + 256));
+        ctx->S_vols = plan_all.n_dirs;
+    }
     if (fuse) {
         plan.n_dirs = plan_all.n_dirs - 1;
         for (int k = plan.n_dirs; k < VO_MAX_DIRS; k++) plan.first_wave[k + 1] = plan.first_wave[plan.n_dirs];
@@ -1027,19 +1098,12 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
     if (vol > ctx->vol_cells || e.D > 256)
         return vo_fail(ctx, VO_E_CAP, "cost volume %zu cells exceeds the capacity given to vo_create (or D > 256)", vol);
     const PathPlan plan = make_plan(g, e.mode);
-    if (plan.n_dirs > ctx->S_vols) {
-        // MODE_HH needs 8 path volumes; grow once
-        if (ctx->S) (void)hipFree(ctx->S);
-        ctx->S = nullptr; ctx->S_vols = 0;
-        VO_HIP(ctx, hipMalloc((void**)&ctx->S, ctx->vol_cells * sizeof(int16_t) * plan.n_dirs + 256));
-        ctx->S_vols = plan.n_dirs;
-    }
     ctx->last_cells = (int64_t)g.W1 * h * g.D;
     ctx->last_paths = (ctx->tune_fuse_wta && g.ur < 100) ? plan.n_dirs - 1 : plan.n_dirs;   // directions inside the k_sgbm_paths launch
     {
         StageTimer t(ctx, VO_T_SGBM_COST);
         hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
-                           ctx->planesL, ctx->planesR, ctx->ccl_size);
+                           ctx->planesL, ctx->planesR, ctx->ccl_size, ctx->rs_ctl, ctx->rs_ctl_words);
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
         const int TY = ctx->tune_sweep_ty;
         const int nw = bx / 64;

@@ -155,8 +155,15 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->planesL, npx * 2); DALLOC(ctx->planesR, npx * 6);
     ctx->vol_cells = npx * (size_t)((max_disp + 31) & ~31);
     DALLOC(ctx->C, ctx->vol_cells);
-    DALLOC(ctx->S, ctx->vol_cells * 5);   // one volume per MODE_SGBM path; grown to 8 for MODE_HH
-    ctx->S_vols = 5;
+    if (const char* e9 = getenv("VO_RASTER")) ctx->tune_raster = atoi(e9) ? 1 : 0;
+    // raster scheme: one extra volume (the E direction, or the reverse pass's sum); the line-per-direction
+    // scheme stores one volume per direction (grown on demand)
+    ctx->S_vols = ctx->tune_raster ? 1 : 5;
+    DALLOC(ctx->S, ctx->vol_cells * ctx->S_vols);
+    DALLOC(ctx->rs_bnd, ctx->vol_cells / 4 + 4096);      // uint64 words: one volume's worth of bytes
+    ctx->rs_ctl_words = 2 * (4 + max_h / 4 + 4);
+    DALLOC(ctx->rs_ctl, ctx->rs_ctl_words);
+    VO_HIP(ctx, hipMemset(ctx->rs_ctl, 0, ctx->rs_ctl_words * sizeof(int)));
     DALLOC(ctx->disp_tmp, npx); DALLOC(ctx->dump, 4096);
     DALLOC(ctx->ccl_label, npx); DALLOC(ctx->ccl_size, npx); DALLOC(ctx->ccl_runlen, npx);
     // ORB: 8-level pyramid is < 3.2x the base image
@@ -206,7 +213,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         if (f.ready) (void)hipEventDestroy(f.ready);
     }
     void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
-                   ctx->C, ctx->S, ctx->disp_tmp, ctx->dump, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
+                   ctx->C, ctx->S, ctx->rs_bnd, ctx->rs_ctl, ctx->disp_tmp, ctx->dump, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
                    ctx->m_idx, ctx->m_dist, ctx->pts_a, ctx->pts_b, ctx->st_a, ctx->st_b, ctx->xy_a, ctx->xy_b,
                    ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws, ctx->ransac_ws };
     for (void* p : ps) if (p) (void)hipFree(p);
@@ -219,7 +226,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     if (ctx->sgbm_done) (void)hipEventDestroy(ctx->sgbm_done);
     for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) {
         vo_ctx::SgbmWs& a = ctx->ws_alt[k];
-        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->la_stage[k] };
+        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.rs_bnd, a.rs_ctl, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->la_stage[k] };
         for (void* q : pa) if (q) (void)hipFree(q);
         if (a.done) (void)hipEventDestroy(a.done);
         orb_ws_free(a.orb);
@@ -443,6 +450,7 @@ static void engine_swap(vo_ctx* ctx, int engine)
     if (engine == 0) return;
     std::swap(ctx->planesL, a.planesL); std::swap(ctx->planesR, a.planesR);
     std::swap(ctx->C, a.C); std::swap(ctx->S, a.S); std::swap(ctx->S_vols, a.S_vols);
+    std::swap(ctx->rs_bnd, a.rs_bnd); std::swap(ctx->rs_ctl, a.rs_ctl);
     std::swap(ctx->disp_tmp, a.disp_tmp);
     std::swap(ctx->ccl_runlen, a.ccl_runlen); std::swap(ctx->ccl_label, a.ccl_label); std::swap(ctx->ccl_size, a.ccl_size);
     std::swap(ctx->sgbm_done, a.done); std::swap(ctx->sgbm_done_valid, a.done_valid);
@@ -458,12 +466,15 @@ static int engine_prepare(vo_ctx* ctx, int engine)
     if (engine == 0 || ctx->ws_alt[engine].ready) return VO_OK;
     vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
     const size_t npx = (size_t)ctx->max_w * ctx->max_h;
-    const int vols = ctx->S_vols > 5 ? ctx->S_vols : 5;
+    const int vols = ctx->S_vols;
     VO_HIP(ctx, hipMalloc((void**)&a.planesL, npx * 2 * 4 + 256));
     VO_HIP(ctx, hipMalloc((void**)&a.planesR, npx * 6 * 4 + 256));
     VO_HIP(ctx, hipMalloc((void**)&a.C, ctx->vol_cells * 2 + 256));
     VO_HIP(ctx, hipMalloc((void**)&a.S, ctx->vol_cells * 2 * vols + 256));
     a.S_vols = vols;
+    VO_HIP(ctx, hipMalloc((void**)&a.rs_bnd, (ctx->vol_cells / 4 + 4096) * 8 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&a.rs_ctl, ctx->rs_ctl_words * sizeof(int) + 256));
+    VO_HIP(ctx, hipMemset(a.rs_ctl, 0, ctx->rs_ctl_words * sizeof(int)));
     VO_HIP(ctx, hipMalloc((void**)&a.disp_tmp, npx * 2 + 256));
     VO_HIP(ctx, hipMalloc((void**)&a.ccl_runlen, npx * 4 + 256));
     VO_HIP(ctx, hipMalloc((void**)&a.ccl_label, npx * 4 + 256));
@@ -760,6 +771,29 @@ extern "C" int vo_get_timings(vo_ctx* ctx, double* ms_out, int64_t* launches_out
         if (launches_out) launches_out[i] = ctx->t_n[i];
         if (reset) { ctx->t_ms[i] = 0; ctx->t_n[i] = 0; }
     }
+    return VO_OK;
+}
+
+extern "C" int vo_sgbm_raster_status(vo_ctx* ctx, int* error_out)
+{
+    if (!ctx || !error_out) return VO_E_ARG;
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = vo_synchronize(ctx);
+    if (rc) return rc;
+    // word 1 of each control block of every workspace: set (and never cleared) when a wait inside a raster
+    // sweep exceeded its poll limit
+    int any = 0;
+    int* blocks[vo_ctx::MAX_ENGINES + 1] = { ctx->rs_ctl };
+    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) blocks[k + 1] = ctx->ws_alt[k].rs_ctl;
+    for (int* b : blocks) {
+        if (!b) continue;
+        for (int half = 0; half < 2; half++) {
+            int v = 0;
+            VO_HIP(ctx, hipMemcpy(&v, b + half * (ctx->rs_ctl_words / 2) + 1, sizeof(int), hipMemcpyDeviceToHost));
+            any |= v;
+        }
+    }
+    *error_out = any;
     return VO_OK;
 }
 

@@ -74,6 +74,8 @@ struct vo_ctx {
         int16_t *C = nullptr, *S = nullptr, *disp_tmp = nullptr;
         int32_t *ccl_runlen = nullptr, *ccl_label = nullptr, *ccl_size = nullptr;
         int S_vols = 0;
+        uint64_t* rs_bnd = nullptr;
+        int* rs_ctl = nullptr;
         hipEvent_t done = nullptr;
         bool done_valid = false;
         bool ready = false;
@@ -119,6 +121,9 @@ struct vo_ctx {
     int S_vols = 0;                // path volumes allocated behind S
     int16_t* disp_tmp = nullptr;   // WTA output before the LR check
     int16_t* dump = nullptr;       // sink for the stores of lanes past the end of their scan line
+    uint64_t* rs_bnd = nullptr;    // raster sweep: bottom-row records handed from band to band (one volume's worth)
+    int* rs_ctl = nullptr;         // raster sweep: two control blocks {ticket, error, -, -, progress[bands]}
+    int rs_ctl_words = 0;
     int32_t* ccl_runlen = nullptr;
     int32_t* ccl_label = nullptr;
     int32_t* ccl_size = nullptr;
@@ -189,6 +194,7 @@ struct vo_ctx {
     // tuning knobs (environment: VO_PATH_PF, VO_SWEEP_XT, VO_SWEEP_TY), read once in vo_create
     int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 15;
     int tune_fuse_wta = 1;          // VO_FUSE_WTA: last (top-down vertical) path fused with the WTA
+    int tune_raster = 1;            // VO_RASTER: W/NW/N/NE (+ WTA) in one raster pass instead of one line sweep per direction
 
     // timing
     bool timing = false;

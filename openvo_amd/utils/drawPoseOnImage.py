@@ -2,7 +2,8 @@
 
 Out of the hot path (marked out of scope): the reference rasterises the
 text with cv2.putText (Hershey font).  When cv2 is importable the same four lines are drawn at
-the same places; otherwise the image is returned unchanged and pose_text(T) gives the lines.
+the same places; otherwise the image is left unchanged and pose_text(T) gives the lines.  Returns None like the reference
+(it draws in place).
 """
 import numpy as np
 
@@ -25,9 +26,9 @@ def drawPoseOnImage(T, img):
     try:
         import cv2
     except ImportError:
-        return img
+        return None          # nothing drawn; the reference returns None as well (it draws in place)
     h = img.shape[0]
     for line, dy, scale in zip(pose_text(T), (180, 120, 60, 10), (2.0, 2.0, 2.0, 1.6)):
         cv2.putText(img, text=line, org=(0, h - dy), fontFace=cv2.FONT_HERSHEY_SIMPLEX, fontScale=scale,
                     color=(0, 0, 255), thickness=3)
-    return img
+    return None              # in place, like the reference [utils/drawPoseOnImage.py:5-38]
