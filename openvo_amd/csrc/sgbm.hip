@@ -29,6 +29,7 @@
 //   k_lr_median3   left-right consistency check evaluated inside medianBlur(3)
 //   k_ccl_*        filterSpeckles (run-based union-find labelling)
 #include "vo_internal.h"
+#include <type_traits>
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -959,7 +960,7 @@ template <int NP, bool PAD, bool REV, bool HASIN, bool WTA>
 static int launch_raster(vo_ctx* ctx, const SgbmGeom& g, const int16_t* Lin, int16_t* Sout, int* ctl)
 {
     const int R = raster_rows(NP), nbands = div_up(g.H, R);
-    const size_t lds = (size_t)(R + 1) * RS_RING * NP * 256 + (size_t)(R + 1) * RS_RING * 16 + (size_t)(16 + ((R + 3) & ~3)) * 4 +
+    const size_t lds = (size_t)(R + 1) * RS_RING * NP * 256 + (size_t)(R + 1) * RS_RING * 16 + (size_t)32 * 4 +
                        (size_t)R * 2 * 4 * g.Dp * 2;
     auto kern = k_sgbm_raster<NP, PAD, REV, HASIN, WTA>;
     static bool attr_set = false;     // per instantiation: allow more than 64 KB of dynamic LDS
@@ -1000,7 +1001,9 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
                     hipLaunchKernelGGL((k_sgbm_paths<NP, 4>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, pe, ctx->dump);
                 VO_CHECK_LAUNCH(ctx);
             } else {
-                if ((rc = launch_raster<NP, false, true, false, false>(ctx, g, nullptr, ctx->S, ctlA))) return rc;
+                if (g.D == g.Dp) rc = launch_raster<NP, false, true, false, false>(ctx, g, nullptr, ctx->S, ctlA);
+                else rc = launch_raster<NP, true, true, false, false>(ctx, g, nullptr, ctx->S, ctlA);
+                if (rc) return rc;
             }
         }
         {

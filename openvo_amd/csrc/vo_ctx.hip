@@ -794,6 +794,14 @@ extern "C" int vo_sgbm_raster_status(vo_ctx* ctx, int* error_out)
         }
     }
     *error_out = any;
+    if (getenv("VO_RASTER_STATS")) {
+        std::vector<int> h(ctx->rs_ctl_words);
+        VO_HIP(ctx, hipMemcpy(h.data(), ctx->rs_ctl, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+        const int half = ctx->rs_ctl_words / 2;
+        for (int b = 0; b < 2; b++)
+            fprintf(stderr, "raster ctl %d: ticket %d err %d slow_above %d slow_below %d spins(any slot) %d %d %d\n", b, h[b * half], h[b * half + 1],
+                    h[b * half + 2], h[b * half + 3], h[b * half + 4 + 8], h[b * half + 4 + 90], h[b * half + 4 + 192]);
+    }
     return VO_OK;
 }
 

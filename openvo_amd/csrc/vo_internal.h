@@ -194,7 +194,8 @@ struct vo_ctx {
     // tuning knobs (environment: VO_PATH_PF, VO_SWEEP_XT, VO_SWEEP_TY), read once in vo_create
     int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 15;
     int tune_fuse_wta = 1;          // VO_FUSE_WTA: last (top-down vertical) path fused with the WTA
-    int tune_raster = 1;            // VO_RASTER: W/NW/N/NE (+ WTA) in one raster pass instead of one line sweep per direction
+    int tune_raster = 0;            // VO_RASTER=1: W/NW/N/NE (+ WTA) in one raster pass instead of one line sweep per direction
+                                    // (6 instead of 14 volume passes, but a W1 + 2H step dependency chain: slower per pair today)
 
     // timing
     bool timing = false;
