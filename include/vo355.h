@@ -214,6 +214,27 @@ int vo_sgbm_last_geometry(vo_ctx* ctx, int64_t* cells, int* n_paths);
  * ever exceeded its poll limit (the affected disparities are then undefined); sticky until vo_destroy */
 int vo_sgbm_raster_status(vo_ctx* ctx, int* error_out);
 
+/* multi-GPU ----------------------------------------------------------------------------
+ * NOT part of the reference (openVO is one process on one thread): frame pairs shard across the GPUs of a
+ * node, one process per GPU, each running its own context on a contiguous chunk of the stream; the path's
+ * only exchange is the gather of the relative poses -- 17 float64 per frame: the row-major 4x4 transform
+ * one accepted update() multiplied into c_T_w [stereo_odometer.py:137-138,146-149] and the accept flag --
+ * done with RCCL (ncclAllGather over xGMI), bound directly: librccl.so.1 is loaded on first use.  Rank 0
+ * obtains the 128-byte id with vo_mgpu_unique_id and hands it to the other ranks by any means (the Python
+ * host uses a TCP socket on the node); every rank then calls vo_mgpu_create with the same id. */
+typedef struct vo_mgpu vo_mgpu;
+int vo_device_count(int* n_out);                       /* HIP devices visible to this process (0 if none) */
+int vo_mgpu_unique_id(uint8_t* id128 /*128 bytes*/);   /* ncclGetUniqueId */
+int vo_mgpu_create(int device, int rank, int world, const uint8_t* id128, vo_mgpu** out);   /* ncclCommInitRank */
+void vo_mgpu_destroy(vo_mgpu* g);
+const char* vo_mgpu_last_error(const vo_mgpu* g);      /* g may be NULL: error of the last failed create / id call */
+/* every rank passes n_frames x 17 float64 (same n_frames on every rank); all_n17 receives world x n_frames x 17
+ * in rank order */
+int vo_mgpu_gather_poses(vo_mgpu* g, const double* local_n17, int n_frames, double* all_n17);
+int vo_mgpu_all_gather_f64(vo_mgpu* g, const double* local, int n, double* all /*world*n*/);
+/* element-wise max over the ranks, in place (the slowest rank's time of a benchmark; doubles as a barrier) */
+int vo_mgpu_all_reduce_max_f64(vo_mgpu* g, double* v, int n);
+
 #ifdef __cplusplus
 }
 #endif

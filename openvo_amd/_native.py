@@ -28,6 +28,8 @@ SYMBOLS = [
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
     "vo_sgbm_last_geometry", "vo_sgbm_raster_status",
+    "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_last_error",
+    "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
 ]
 
 
@@ -41,7 +43,7 @@ class VoError(RuntimeError):
 
 def build_native(force=False):
     """Compile openvo_amd/csrc/*.hip for gfx950 into openvo_amd/libvo355.so."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h", ".inc"))]
     srcs.append(os.path.join(_HERE, "..", "include", "vo355.h"))
     srcs.append(os.path.join(_HERE, "..", "include", "vo_orb_pattern.inc"))
     newest = max(os.path.getmtime(s) for s in srcs)
@@ -109,6 +111,16 @@ def lib():
         L.vo_get_timings.argtypes = [vp, vp, vp, ci]
         L.vo_sgbm_last_geometry.argtypes = [vp, vp, vp]
         L.vo_sgbm_raster_status.argtypes = [vp, vp]
+        L.vo_device_count.argtypes = [vp]
+        L.vo_mgpu_unique_id.argtypes = [vp]
+        L.vo_mgpu_create.argtypes = [ci, ci, ci, vp, vp]
+        L.vo_mgpu_destroy.restype = None
+        L.vo_mgpu_destroy.argtypes = [vp]
+        L.vo_mgpu_last_error.restype = ctypes.c_char_p
+        L.vo_mgpu_last_error.argtypes = [vp]
+        L.vo_mgpu_gather_poses.argtypes = [vp, vp, ci, vp]
+        L.vo_mgpu_all_gather_f64.argtypes = [vp, vp, ci, vp]
+        L.vo_mgpu_all_reduce_max_f64.argtypes = [vp, vp, ci]
         _lib = L
     return _lib
 

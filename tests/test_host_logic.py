@@ -1,11 +1,9 @@
-"""Host-side logic that needs no GPU: rectification setup, sharding + pose gather (gloo, 2 ranks)."""
+"""Host-side logic that needs no GPU: rectification setup (sharding: tests/test_sharding.py)."""
 import os
-import subprocess
-import sys
 
 import numpy as np
 
-from openvo_amd import calib, sharding
+from openvo_amd import calib
 from openvo_amd.synth import Corridor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,61 +45,3 @@ def test_rectify_rotated_rig_is_consistent():
     xd = x * kr + 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x)
     yd = y * kr + k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y
     assert np.allclose(np.stack([xd * c.f + c.cx, yd * c.f + c.cy], 1), pts, atol=1e-6)
-
-
-def test_shard_ranges_cover_everything():
-    for n, world in [(256, 8), (10, 4), (7, 2), (3, 8)]:
-        spans = [sharding.shard_range(n, r, world) for r in range(world)]
-        assert spans[0][0] == 0 and spans[-1][1] == n
-        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
-        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
-
-
-def test_compose_matches_sequential_chain():
-    rng = np.random.default_rng(0)
-    c_T_w = np.eye(4)
-    rel, ok, poses = [], [], []
-    for k in range(12):
-        T = np.eye(4)
-        T[:3, :3] = calib.rodrigues_vec_to_mat(rng.normal(scale=0.01, size=3))
-        T[:3, 3] = rng.normal(scale=0.1, size=3)
-        acc = k % 5 != 3
-        before = c_T_w.copy()
-        if acc:
-            c_T_w = T @ c_T_w
-            assert np.allclose(sharding.relative_from_chain(before, c_T_w), T, atol=1e-12)
-        rel.append(T); ok.append(acc); poses.append(np.linalg.inv(c_T_w))
-    assert np.allclose(sharding.compose(rel, ok), poses, atol=1e-12)
-
-
-_WORKER = r'''
-import os, sys
-sys.path.insert(0, %r)
-import numpy as np, torch.distributed as dist
-from openvo_amd import sharding
-dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
-r, w = dist.get_rank(), dist.get_world_size()
-n = 5
-lo, hi = sharding.shard_range(n * w, r, w)
-T = np.tile(np.eye(4), (n, 1, 1)); T[:, 2, 3] = -0.25 * (np.arange(lo, hi) + 1); ok = np.ones(n); ok[1] = r
-allT, allok = sharding.gather_relative(T, ok, dist)
-if r == 0:
-    assert allT.shape == (n * w, 4, 4) and allok.shape == (n * w,)
-    assert np.allclose(allT[:, 2, 3], -0.25 * (np.arange(n * w) + 1))
-    assert allok.tolist() == [True, False, True, True, True, True, True, True, True, True]
-    poses = sharding.compose(allT, allok)
-    assert abs(poses[-1][2, 3] - 0.25 * (sum(range(1, 11)) - 2)) < 1e-12
-    print("GATHER_OK")
-dist.barrier(); dist.destroy_process_group()
-'''
-
-
-def test_pose_gather_two_ranks_gloo(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK" in outs[0]

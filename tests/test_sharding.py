@@ -1,0 +1,247 @@
+"""Multi-GPU host logic on CPU (BASELINE config 3): the socket transport of openvo_amd.sharding
+(no torch, no GPU) and what sharding can break -- the history the reference's update() carries from frame to
+frame (/root/reference/src/openVO/stereo_odometer.py:137-160,215-220).  Two / three shard processes run a
+scripted ("fake frame") StereoOdometer: the REAL update() state machine of openvo_amd with stand-ins for the
+camera, ORB and the pair solver, so every decision (which frames pair up, fallback, gate widening) is the
+product's own."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from openvo_amd import calib, sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(script, world, tmp_path, args=()):
+    path = tmp_path / "worker.py"
+    path.write_text(script)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, str(path)] + [str(a) for a in args], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return outs
+
+
+def test_shard_ranges_cover_everything():
+    for n, world in [(256, 8), (10, 4), (7, 2), (3, 8)]:
+        spans = [sharding.shard_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+_PRIMS = r'''
+import os, sys
+import numpy as np
+from openvo_amd import sharding
+assert "torch" not in sys.modules
+g, dev = sharding.init_from_env()
+r, w = g.rank, g.world
+assert g.transport == "socket"                       # no GPU here: the sockets carry everything
+parts = g.all_gather_bytes(bytes([r]) * (r + 1))     # ragged payloads
+assert parts == [bytes([i]) * (i + 1) for i in range(w)]
+g.barrier()
+assert g.broadcast_bytes(b"id-%d" % r, root=1) == b"id-1"
+assert g.all_reduce_max(1.5 + r) == 1.5 + (w - 1)
+a = g.all_gather_f64(np.arange(4) + 10 * r)
+assert a.shape == (w, 4) and np.array_equal(a[:, 0], 10 * np.arange(w))
+n = 5
+T = np.tile(np.eye(4), (n, 1, 1)); T[:, 2, 3] = -0.25 * (np.arange(r * n, r * n + n) + 1); ok = np.ones(n); ok[1] = r != 0
+allT, allok = g.gather_relative(T, ok)
+assert allT.shape == (n * w, 4, 4) and allok.shape == (n * w,)
+assert np.allclose(allT[:, 2, 3], -0.25 * (np.arange(n * w) + 1))
+assert allok.tolist() == [True, False, True, True, True] + [True] * (n * (w - 1))
+poses = sharding.compose(allT, allok)
+assert abs(poses[-1][2, 3] - 0.25 * (sum(range(1, n * w + 1)) - 2)) < 1e-12
+assert "torch" not in sys.modules
+g.close()
+print("PRIMS_OK")
+'''
+
+
+def test_socket_group_primitives_three_ranks(tmp_path):
+    outs = _spawn(_PRIMS, 3, tmp_path)
+    assert all("PRIMS_OK" in o for o in outs)
+
+
+# ---- a scripted odometer: openvo_amd's own update() with stand-ins around it ----------------------------------
+_FAKE = r'''
+import numpy as np
+from openvo_amd import StereoOdometer, calib
+
+
+def motions(n, seed=7):
+    """True frame-to-frame motion M_k (frame k-1 -> k), k = 1..n-1; M_0 unused."""
+    rng = np.random.default_rng(seed)
+    out = [np.eye(4)]
+    for k in range(1, n):
+        T = np.eye(4)
+        T[:3, :3] = calib.rodrigues_vec_to_mat(rng.normal(scale=0.01, size=3))
+        T[:3, 3] = [rng.normal(scale=0.02), rng.normal(scale=0.01), -0.25 + rng.normal(scale=0.01)]
+        out.append(T)
+    return out
+
+
+class FakeStereo:
+    def compute_3d(self, left, right, preprocessed=False):
+        k = int(left)                                       # a "frame" is just its index
+        return ("xyz", k), np.full((2, 2), 10.0, np.float32), ("img", k)
+
+
+class FakeOrb:
+    def __init__(self, nkp):
+        self.nkp = nkp
+
+    def detectAndCompute(self, img, mask):
+        k = img[1]
+        return [None] * self.nkp.get(k, 50), ("desc", k)
+
+
+class ScriptedOdometer(StereoOdometer):
+    """The pair solver is scripted: T(a -> b) is the product of the true motions, or None for the frame
+    pairs listed in `fail` (as if too few matches survived)."""
+
+    def __init__(self, M, fail=(), nkp=None):
+        super().__init__(FakeStereo(), preprocessed_frames=True)
+        self.orb, self.M, self.fail = FakeOrb(nkp or {}), M, set(fail)
+        self.pairs_tried = []
+
+    def _try_pair(self, kps_a, desc_a, im3d_a, kps_b, desc_b, im3d_b):
+        a, b = desc_a[1], desc_b[1]
+        self.pairs_tried.append((a, b))
+        if (a, b) in self.fail:
+            self.skip_cause = "matches"
+            return None
+        T = np.eye(4)
+        for k in range(a + 1, b + 1):
+            T = self.M[k] @ T
+        return self._gate_like_reference(T)
+
+    def _gate_like_reference(self, T):
+        # the reference's motion gate on the translation, widened by skipped_frames [stereo_odometer.py:215-218]
+        if np.linalg.norm(T[:3, 3]) > self.MAX_DISTANCE_CHANGE * (self.skipped_frames + 1):
+            self.skip_cause = "bigdist"
+            return None
+        return T
+
+
+def run_frames(M, frames, fail=(), nkp=None):
+    """-> (relative transforms, accept flags, c_T_w after every frame) for the frame indices given."""
+    from openvo_amd import sharding
+    odo = ScriptedOdometer(M, fail, nkp)
+    rel, ok, chain = [], [], []
+    for k in frames:
+        before = odo.c_T_w
+        a = odo.update(k, k)
+        ok.append(bool(a))
+        rel.append(sharding.relative_from_chain(before, odo.c_T_w) if a else np.eye(4))
+        chain.append(odo.c_T_w.copy())
+    return np.array(rel), np.array(ok), chain, odo
+'''
+
+_SHARD = _FAKE + r'''
+import json, os, sys
+from openvo_amd import sharding
+assert "torch" not in sys.modules
+case = json.loads(sys.argv[1])
+n_local, fail, nkp = case["n_local"], [tuple(p) for p in case["fail"]], {int(k): v for k, v in case["nkp"].items()}
+g, _ = sharding.init_from_env()
+N = n_local * g.world
+M = motions(N)
+lo, hi = g.rank * n_local, (g.rank + 1) * n_local
+frames = list(range(lo, hi)) if g.rank == 0 else list(range(lo - 1, hi))     # one halo frame
+rel, ok, chain, odo = run_frames(M, frames, fail, nkp)
+if g.rank > 0:
+    rel, ok = rel[1:], ok[1:]                                                # the halo frame belongs to the previous shard
+allT, allok = g.gather_relative(rel, ok)
+if g.rank == 0:
+    poses = sharding.compose(allT, allok)
+    _, sok, schain, _ = run_frames(M, range(N), fail, nkp)                   # the sequential reference chain
+    seq = np.array([np.linalg.inv(c) for c in schain])
+    report = sharding.boundary_report(allok, n_local, g.world)
+    print("RESULT " + json.dumps({"max_err": float(np.abs(poses - seq).max()), "accepted": allok.tolist(), "seq_accepted": sok.tolist(),
+                                  "report": report}))
+g.close()
+'''
+
+
+def _run_case(tmp_path, world, case):
+    import json
+    outs = _spawn(_SHARD, world, tmp_path, args=[json.dumps(case)])
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT ")][0]
+    return json.loads(line[7:])
+
+
+def test_two_shards_compose_to_the_sequential_trajectory(tmp_path):
+    """No frame rejected at a chunk boundary: the gathered relative transforms compose to exactly the chain a
+    single sequential odometer builds -- also with a frame rejected INSIDE a shard (the next frame then pairs
+    with the older one, in both runs) and a frame with too few keypoints."""
+    res = _run_case(tmp_path, 2, {"n_local": 8, "fail": [[2, 3], [1, 3]], "nkp": {"12": 3}})
+    assert res["accepted"] == res["seq_accepted"]
+    assert res["accepted"][3] is False and res["accepted"][12] is False and sum(res["accepted"]) == 14
+    assert res["report"] == [] and res["max_err"] < 1e-12
+
+
+def test_three_shards_all_accepted(tmp_path):
+    res = _run_case(tmp_path, 3, {"n_local": 5, "fail": [], "nkp": {}})
+    assert all(res["accepted"]) and res["report"] == [] and res["max_err"] < 1e-12
+
+
+def test_rejected_frame_at_the_chunk_boundary_is_detected_and_reported(tmp_path):
+    """The case sharding cannot make exact: the last frame of shard 0 (the halo of shard 1) is rejected.
+    Sequentially frame 8 pairs with frame 6; shard 1 starts from frame 7 as if it had been accepted.  The
+    composed trajectory then differs -- and boundary_report says so, naming the shard and the frame."""
+    res = _run_case(tmp_path, 2, {"n_local": 8, "fail": [[6, 7], [5, 7]], "nkp": {}})
+    assert res["accepted"][7] is False and res["seq_accepted"][7] is False
+    assert len(res["report"]) == 1 and res["report"][0]["shard"] == 1 and res["report"][0]["frame"] == 8
+    assert "halo frame 7 was rejected" in res["report"][0]["cause"]
+    assert res["max_err"] > 1e-3                      # the inexactness is real, which is why it must be reported
+
+
+def test_first_step_of_a_shard_rejected_is_reported(tmp_path):
+    """Frame 8 cannot pair with frame 7 but could with frame 6 (the fallback): the sequential run recovers
+    through `prev`, shard 1 has no `prev` yet."""
+    res = _run_case(tmp_path, 2, {"n_local": 8, "fail": [[7, 8]], "nkp": {}})
+    assert res["seq_accepted"][8] is True and res["accepted"][8] is False
+    assert [r["frame"] for r in res["report"]] == [8] and "fallback" in res["report"][0]["cause"]
+
+
+def test_compose_matches_sequential_chain():
+    rng = np.random.default_rng(0)
+    c_T_w = np.eye(4)
+    rel, ok, poses = [], [], []
+    for k in range(12):
+        T = np.eye(4)
+        T[:3, :3] = calib.rodrigues_vec_to_mat(rng.normal(scale=0.01, size=3))
+        T[:3, 3] = rng.normal(scale=0.1, size=3)
+        acc = k % 5 != 3
+        before = c_T_w.copy()
+        if acc:
+            c_T_w = T @ c_T_w
+            assert np.allclose(sharding.relative_from_chain(before, c_T_w), T, atol=1e-12)
+        rel.append(T); ok.append(acc); poses.append(np.linalg.inv(c_T_w))
+    assert np.allclose(sharding.compose(rel, ok), poses, atol=1e-12)
+
+
+def test_single_process_group_is_the_identity():
+    g = sharding.Group(0, 1)
+    T = np.tile(np.eye(4), (3, 1, 1))
+    a, ok = g.gather_relative(T, [1, 0, 1])
+    assert a.shape == (3, 4, 4) and ok.tolist() == [True, False, True]
+    assert g.all_reduce_max(2.5) == 2.5 and g.all_gather_bytes(b"x") == [b"x"]
+    b, ok2 = sharding.gather_relative(T, [1, 1, 1])
+    assert b.shape == (3, 4, 4) and ok2.all()
