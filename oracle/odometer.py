@@ -14,10 +14,13 @@ from . import oracle as O
 
 
 class RefStereoCamera:
-    def __init__(self, Q, roi, sgbm_params, maps=None, mode=0):
+    def __init__(self, Q, roi, sgbm_params, maps=None, mode=0, dense_3d=False):
+        """dense_3d: also evaluate reprojectImageTo3D on the whole image, as the reference does on every
+        pair (stereo_camera.py:52) -- the timed CPU baseline sets it; the sampled values are the same."""
         self.Q = np.asarray(Q, np.float64)
         self.valid_region_left = tuple(roi)
         self.sgbm_params, self.mode, self.maps = dict(sgbm_params), mode, maps
+        self.dense_3d = dense_3d
 
     def crop(self, img):
         vr = self.valid_region_left
@@ -35,6 +38,9 @@ class RefStereoCamera:
         disparity = disp16.astype(np.float32) / 16               # :51
         self.last_disp16 = disp16
         img_3d = _Lazy3D(disp16, self.Q, self.valid_region_left)  # :52 (evaluated where sampled)
+        if self.dense_3d:
+            with np.errstate(all="ignore"):
+                self.last_dense = O.reproject_to_3d(disparity, self.Q)   # the full image, like cv2.reprojectImageTo3D
         return img_3d, self.crop(disparity), self.crop(img_left)
 
 
