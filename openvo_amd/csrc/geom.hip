@@ -1117,14 +1117,21 @@ __global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* _
 }
 
 // enqueue the whole fused step for two slots on ctx->stream with the scratch currently installed in ctx; the
+size_t pose_ws_bytes(int nq)
+{
+    const int words = (nq + 63) / 64;
+    return (size_t)nq * words * 8 + (size_t)nq * 4 + (size_t)nq * 12 * 4 + (size_t)nq * 8 + 4096;
+}
+
 // PoseOut record is copied to host_out (pinned) at the end.  No host synchronisation.
 static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, int min_matches, double rigidity_thr,
                         double outlier_thr, void* host_out)
 {
     const int nq = a.n_kp;
-    // workspace: bit matrix + ncons + filtered point sets + residuals + result
+    // workspace: bit matrix + ncons + filtered point sets + residuals + result.  vo_create / pose_alt_prepare size it
+    // for kp_cap query keypoints, so the branch below (a device-wide synchronisation) is never taken on the hot path
     const int words = (nq + 63) / 64;
-    const size_t need = (size_t)nq * words * 8 + (size_t)nq * 4 + (size_t)nq * 12 * 4 + (size_t)nq * 8 + 4096;
+    const size_t need = pose_ws_bytes(nq);
     if (ctx->clique_ws_bytes < need) {
         if (ctx->clique_ws) { VO_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->clique_ws); }
         ctx->clique_ws = nullptr; ctx->clique_ws_bytes = 0;
@@ -1241,6 +1248,8 @@ static int pose_alt_prepare(vo_ctx* ctx, int k)
     VO_HIP(ctx, hipMalloc((void**)&p.pts_a, cap * 12 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.pts_b, cap * 12 + 256));
     VO_HIP(ctx, hipMalloc((void**)&p.xy_a, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.xy_b, cap * 8 + 256));
     VO_HIP(ctx, hipMalloc((void**)&p.st_a, cap + 256)); VO_HIP(ctx, hipMalloc((void**)&p.st_b, cap + 256));
+    p.clique_ws_bytes = pose_ws_bytes(ctx->kp_cap);
+    VO_HIP(ctx, hipMalloc((void**)&p.clique_ws, p.clique_ws_bytes));
     p.ready = true;
     return VO_OK;
 }
@@ -1278,14 +1287,19 @@ extern "C" int vo_pose_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
     // the step runs on the alternate's own stream: order it behind whatever still produces the two slots
     // (look-ahead engines) and behind the main stream's work on them
     VO_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    pose_swap(ctx, k);
-    hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev0, 0);
-    if (e == hipSuccess && a.pending) e = hipStreamWaitEvent(ctx->stream, a.ready, 0);
-    if (e == hipSuccess && b.pending) e = hipStreamWaitEvent(ctx->stream, b.ready, 0);
-    rc = e == hipSuccess ? VO_OK : vo_fail(ctx, VO_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
-    if (!rc && a.n_kp > 0) rc = pose_enqueue(ctx, a, b, ratio, min_matches, rigidity_thr, outlier_thr, rec);
-    if (!rc && hipEventRecord(p.done, ctx->stream) != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
-    pose_swap(ctx, k);
+    {
+        struct PoseScope {      // the context works on alternate k's stream and scratch inside this block, whatever leaves it
+            vo_ctx* c; int k;
+            PoseScope(vo_ctx* c_, int k_) : c(c_), k(k_) { pose_swap(c, k); }
+            ~PoseScope() { pose_swap(c, k); }
+        } on_alt(ctx, k);
+        hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev0, 0);
+        if (e == hipSuccess && a.pending) e = hipStreamWaitEvent(ctx->stream, a.ready, 0);
+        if (e == hipSuccess && b.pending) e = hipStreamWaitEvent(ctx->stream, b.ready, 0);
+        rc = e == hipSuccess ? VO_OK : vo_fail(ctx, VO_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+        if (!rc && a.n_kp > 0) rc = pose_enqueue(ctx, a, b, ratio, min_matches, rigidity_thr, outlier_thr, rec);
+        if (!rc && hipEventRecord(p.done, ctx->stream) != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
+    }
     if (rc) return rc;
     p.busy = true; p.slot_a = slot_a; p.slot_b = slot_b;
     p.params[0] = ratio; p.params[1] = min_matches; p.params[2] = rigidity_thr; p.params[3] = outlier_thr;

@@ -114,9 +114,15 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h)
             ++v0;
         }
     }
+    // The resize tables are one device array shared by the main and all look-ahead streams: extractions still
+    // in flight anywhere read them, so everything queued so far must finish before they are rewritten for a
+    // new image size (rare: once per size).  What those extractions produced stays valid.
+    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++)
+        if (ctx->la_stream[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream[k]));
+    for (int k = 0; k < vo_ctx::N_POSE_ALT; k++)
+        if (ctx->pose_alt[k].stream) VO_HIP(ctx, hipStreamSynchronize(ctx->pose_alt[k].stream));
     VO_HIP(ctx, hipMemcpyAsync(ctx->rs_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     VO_HIP(ctx, hipMemcpyAsync(ctx->rs_coef, coef.data(), coef.size() * 2, hipMemcpyHostToDevice, ctx->stream));
-    VO_HIP(ctx, hipMemcpyAsync(ctx->d_levels, &L, sizeof(L), hipMemcpyHostToDevice, ctx->stream));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     static_assert(sizeof(LevelsDev) <= sizeof(ctx->rs_meta_host), "level table too large");
     memcpy(ctx->rs_meta_host, &L, sizeof(L));
@@ -157,12 +163,12 @@ __device__ __forceinline__ unsigned hrow(const uint8_t* __restrict__ s, int sw, 
 
 // resize(prev, cur, INTER_LINEAR_EXACT) for image and (optionally) mask; mask then
 // threshold(254, THRESH_TOZERO)
-__global__ void k_orb_resize(const LevelsDev* __restrict__ L, int lvl, const int32_t* __restrict__ ofs,
+__global__ void k_orb_resize(const LevelsDev L, int lvl, const int32_t* __restrict__ ofs,
                              const uint16_t* __restrict__ coef, uint8_t* __restrict__ pimg, uint8_t* __restrict__ pmask,
                              int with_mask)
 {
-    const LevelDev d = L->l[lvl];
-    const LevelDev p = L->l[lvl - 1];
+    const LevelDev d = L.l[lvl];
+    const LevelDev p = L.l[lvl - 1];
     int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
     if (dx >= d.w) return;
     const int32_t* xo = ofs + d.xt;
@@ -241,7 +247,7 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int 
 // of the tile and its 1-pixel halo go through LDS only (no score image), wave w then judges rows 4w..4w+3.
 // The survivors of the whole tile reserve their slots with ONE returning global atomic (a per-wave atomic
 // on a single counter serialises at ~12 ns each).
-__global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg,
+__global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev L, const uint8_t* __restrict__ pimg,
                                                       const uint8_t* __restrict__ pmask, int with_mask, int32_t* __restrict__ cand_pos,
                                                       float* __restrict__ cand_resp, int32_t* __restrict__ cnt)
 {
@@ -250,7 +256,7 @@ __global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev* __restric
     __shared__ int s_cnt[16];
     __shared__ int s_base;
     const int lvl = blockIdx.z;
-    const LevelDev d = L->l[lvl];
+    const LevelDev d = L.l[lvl];
     if (d.w <= 2 * EDGE || d.h <= 2 * EDGE) return;  // block-uniform (depends on the level only)
     const int x0 = blockIdx.x * TW + EDGE, y0 = blockIdx.y * TH + EDGE;
     if (x0 >= d.w - EDGE || y0 >= d.h - EDGE) return;  // block-uniform
@@ -301,12 +307,12 @@ __global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev* __restric
 }
 
 // retainBest(2*quota) by FAST score: keep every candidate whose score >= the n-th largest
-__device__ __forceinline__ void orb_fast_select(const LevelsDev* L, const int32_t* cand_pos,
+__device__ __forceinline__ void orb_fast_select(const LevelsDev& L, const int32_t* cand_pos,
                                                 const float* cand_resp, int32_t* candA_pos,
                                                 int32_t* cnt, int* s_hist, int& s_thr, int& s_n)
 {
     const int lvl = blockIdx.x;
-    const LevelDev d = L->l[lvl];
+    const LevelDev d = L.l[lvl];
     const int n = cnt[CNT_CAND + lvl], keep = 2 * d.quota;
     const int32_t* pos = cand_pos + d.cand_off;
     const float* resp = cand_resp + d.cand_off;
@@ -376,14 +382,14 @@ __device__ __forceinline__ unsigned f2key(float f)
 
 // retainBest(quota) by Harris response (radix select of the quota-th largest, ties kept), then
 // sort the survivors by position and stage them per level
-__device__ __forceinline__ void orb_harris_select(const LevelsDev* L, const int32_t* candA_pos,
+__device__ __forceinline__ void orb_harris_select(const LevelsDev& L, const int32_t* candA_pos,
                                                   const float* candA_resp, int32_t* fin_pos,
                                                   float* fin_resp, int32_t* tmp_pos,
                                                   float* tmp_resp, int32_t* cnt, int* hist,
                                                   unsigned& s_prefix, unsigned& s_mask, int& s_remaining, int& s_nf)
 {
     const int lvl = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const LevelDev d = L->l[lvl];
+    const LevelDev d = L.l[lvl];
     const int n = cnt[CNT_A + lvl], keep = d.quota;
     const int32_t* pos = candA_pos + d.cand_off;
     const float* resp = candA_resp + d.cand_off;
@@ -441,7 +447,7 @@ __device__ __forceinline__ void orb_harris_select(const LevelsDev* L, const int3
 // of the survivors -> retainBest(quota) by Harris + canonical order.  (Three launches with a mostly empty
 // grid in the middle before; the phases only ever needed block-level synchronisation.)
 // (fin_* alias cand_*: the final lists replace the NMS lists, which are dead by then -- no __restrict__ here)
-__global__ void __launch_bounds__(1024) k_orb_select(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg,
+__global__ void __launch_bounds__(1024) k_orb_select(const LevelsDev L, const uint8_t* __restrict__ pimg,
                                                      const int32_t* cand_pos, const float* cand_resp,
                                                      int32_t* candA_pos, float* candA_resp, int32_t* fin_pos, float* fin_resp,
                                                      int32_t* tmp_pos, float* tmp_resp, int32_t* cnt)
@@ -451,7 +457,7 @@ __global__ void __launch_bounds__(1024) k_orb_select(const LevelsDev* __restrict
     __shared__ unsigned s_prefix, s_mask;
     orb_fast_select(L, cand_pos, cand_resp, candA_pos, cnt, s_hist, s_thr, s_n);
     __syncthreads();
-    const LevelDev d = L->l[blockIdx.x];
+    const LevelDev d = L.l[blockIdx.x];
     const int nA = s_n;
     for (int i = threadIdx.x; i < nA; i += blockDim.x) orb_harris_one(d, pimg, candA_pos, candA_resp, i);
     __syncthreads();
@@ -505,7 +511,7 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 #define DESC_W (2 * DESC_R + 1)        // 39
 #define DESC_HR (DESC_W + 6)           // 45 rows after the row pass
 #define DESC_LD 40
-__global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev* __restrict__ L, const uint8_t* __restrict__ pimg,
+__global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev L, const uint8_t* __restrict__ pimg,
                                                      const int32_t* __restrict__ fin_pos, const float* __restrict__ fin_resp,
                                                      int32_t* __restrict__ cnt, int cap, float* __restrict__ kp_xy,
                                                      float* __restrict__ kp_size, float* __restrict__ kp_resp,
@@ -524,7 +530,7 @@ __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev* __restric
     }
     if (k == 0 && lane == 0) cnt[CNT_TOTAL] = total;
     if (k >= min(total, cap)) return;
-    const LevelDev d = L->l[lvl];
+    const LevelDev d = L.l[lvl];
     const int w = d.w, pos = fin_pos[d.cand_off + (k - base)];
     if (lane == 0) {
         const int px = pos % w, py = pos / w;
@@ -541,7 +547,7 @@ __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev* __restric
     if (lane <= 2 * HALF_PATCH) {
         const int au = abs(u);
         for (int v = -HALF_PATCH; v <= HALF_PATCH; v++) {
-            if (au <= L->umax[abs(v)]) {
+            if (au <= L.umax[abs(v)]) {
                 int val = ctr[v * w + u];
                 m10 += u * val;
                 m01 += v * val;
@@ -626,12 +632,9 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
         }
         Lh->l[NL - 1].quota = nfeatures - sum > 0 ? nfeatures - sum : 0;
     }
-    if (ctx->orb_quota_nfeatures != nfeatures) {
-        VO_HIP(ctx, hipMemcpyAsync(ctx->d_levels, Lh, sizeof(LevelsDev), hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->orb_quota_nfeatures = nfeatures;
-    }
-    const LevelsDev* dL = (const LevelsDev*)ctx->d_levels;
+    // The level table (geometry + this call's quotas, 452 bytes) travels BY VALUE in every launch: extractions
+    // queued on other engines' streams with other nfeatures keep the quotas they were enqueued with.
+    const LevelsDev dL = *Lh;
     const int with_mask = mask_mode != 0;
     StageTimer t(ctx, VO_T_ORB);
     hipLaunchKernelGGL(k_orb_level0, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_img, img_stride, w, h, mask_mode,

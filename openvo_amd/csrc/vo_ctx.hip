@@ -185,6 +185,8 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->xy_a, (size_t)ctx->kp_cap * 2); DALLOC(ctx->xy_b, (size_t)ctx->kp_cap * 2);
     DALLOC(ctx->mq_idx, ctx->kp_cap); DALLOC(ctx->mt_idx, ctx->kp_cap);
     DALLOC(ctx->red, 4096);
+    ctx->clique_ws_bytes = pose_ws_bytes(ctx->kp_cap);     // sized once: the pose step never reallocates mid-stream
+    DALLOC(ctx->clique_ws, ctx->clique_ws_bytes);
     ctx->pinned_bytes = 8 << 20;
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&ctx->slot_words, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
@@ -194,6 +196,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     if (const char* e3 = getenv("VO_PATH_PF")) { int v = atoi(e3); if (v == 2 || v == 4 || v == 8) ctx->tune_path_pf = v; }
     if (const char* e8 = getenv("VO_ENGINES")) { int v = atoi(e8); if (v >= 1 && v <= vo_ctx::MAX_ENGINES) ctx->n_engines = v; }
     if (const char* e7 = getenv("VO_FUSE_WTA")) ctx->tune_fuse_wta = atoi(e7) ? 1 : 0;
+    if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);
     if (const char* e5 = getenv("VO_SWEEP_XT")) { int v = atoi(e5); if (v == 8 || v == 16) ctx->tune_sweep_xt = v; }
     if (const char* e6 = getenv("VO_SWEEP_TY")) { int v = atoi(e6); if (v >= 4 && v <= 4096) ctx->tune_sweep_ty = v; }
     *out = ctx;
@@ -456,6 +459,18 @@ static void engine_swap(vo_ctx* ctx, int engine)
     std::swap(ctx->sgbm_done, a.done); std::swap(ctx->sgbm_done_valid, a.done_valid);
 }
 
+// Retargets the context at a look-ahead engine for the lifetime of the object.  Whatever path leaves the
+// scope -- a status funnelled through rc or an early return of a VO_HIP check added later -- the context
+// comes back un-crossed.
+struct EngineScope {
+    vo_ctx* ctx;
+    int engine;
+    EngineScope(vo_ctx* c, int e) : ctx(c), engine(e) { engine_swap(ctx, engine); }
+    ~EngineScope() { engine_swap(ctx, engine); }
+    EngineScope(const EngineScope&) = delete;
+    EngineScope& operator=(const EngineScope&) = delete;
+};
+
 static int engine_prepare(vo_ctx* ctx, int engine)
 {
     if (!ctx->la_stream[engine]) {
@@ -519,28 +534,34 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
         kind = hipMemcpyHostToDevice;
     }
     ctx->next_engine = (engine + 1) % ctx->n_engines;
-    engine_swap(ctx, engine);
-    {
-        StageTimer t(ctx, VO_T_UPLOAD);
-        rc = ingest(ctx, 0, srcL, w, h, channels, preprocessed, f.left, ctx->stage_in, kind);
-        if (!rc) rc = ingest(ctx, 1, srcR, w, h, channels, preprocessed, f.right, ctx->stage_in, kind);
-    }
-    if (!rc && from_host) {
-        vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
-        if (hipEventRecord(a.h2d_done, ctx->stream) == hipSuccess) a.h2d_valid = true;
-        else rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
-    }
-    if (!rc) rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
     f.w = w; f.h = h; f.has_kp = false; f.n_kp = 0; f.kp_pending = false;
-    if (!rc && ctx->la_orb) {
-        const int* q = ctx->la_orb_params;
-        rc = orb_slot_enqueue(ctx, f, q[0], q[1], q[2], q[3]);
-        if (!rc) { memcpy(f.kp_params, q, sizeof(f.kp_params)); f.kp_pending = true; }
+    {
+        EngineScope on_engine(ctx, engine);          // ctx->stream / staging / SGBM + ORB workspaces are the engine's in here
+        {
+            StageTimer t(ctx, VO_T_UPLOAD);
+            rc = ingest(ctx, 0, srcL, w, h, channels, preprocessed, f.left, ctx->stage_in, kind);
+            if (!rc) rc = ingest(ctx, 1, srcR, w, h, channels, preprocessed, f.right, ctx->stage_in, kind);
+        }
+        if (!rc && from_host) {
+            vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
+            if (hipEventRecord(a.h2d_done, ctx->stream) == hipSuccess) a.h2d_valid = true;
+            else rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
+        }
+        if (!rc && ctx->fault_prefetch > 0 && --ctx->fault_prefetch == 0)
+            rc = vo_fail(ctx, VO_E_STATE, "injected failure (VO_FAULT_PREFETCH) inside the engine scope");
+        if (!rc) rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
+        if (!rc && ctx->la_orb) {
+            const int* q = ctx->la_orb_params;
+            rc = orb_slot_enqueue(ctx, f, q[0], q[1], q[2], q[3]);
+            if (!rc) { memcpy(f.kp_params, q, sizeof(f.kp_params)); f.kp_pending = true; }
+        }
+        if (!rc && hipEventRecord(f.ready, ctx->stream) != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
     }
-    hipError_t e = rc ? hipSuccess : hipEventRecord(f.ready, ctx->stream);
-    engine_swap(ctx, engine);
-    if (rc) { f.kp_pending = false; return rc; }
-    if (e != hipSuccess) return vo_fail(ctx, VO_E_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+    if (rc) {
+        // the slot holds a half-processed pair: nothing in it may be handed out
+        f.kp_pending = false; f.has_pair = false; f.has_disp = false; f.pending = false;
+        return rc;
+    }
     f.has_pair = true; f.has_disp = true; f.pending = true;
     return VO_OK;
 }

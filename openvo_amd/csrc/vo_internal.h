@@ -193,6 +193,7 @@ struct vo_ctx {
 
     // tuning knobs (environment: VO_PATH_PF, VO_SWEEP_XT, VO_SWEEP_TY), read once in vo_create
     int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 15;
+    int fault_prefetch = 0;         // VO_FAULT_PREFETCH=n (test hook): the n-th look-ahead submission fails inside its engine scope
     int tune_fuse_wta = 1;          // VO_FUSE_WTA: last (top-down vertical) path fused with the WTA
     int tune_raster = 0;            // VO_RASTER=1: W/NW/N/NE (+ WTA) in one raster pass instead of one line sweep per direction
                                     // (6 instead of 14 volume passes, but a W1 + 2H step dependency chain: slower per pair today)
@@ -243,6 +244,7 @@ int xfer_flush(vo_ctx* ctx);
 int slot_wait(vo_ctx* ctx, FrameSlot& f);
 int orb_slot_enqueue(vo_ctx* ctx, FrameSlot& f, int nfeatures, int mask_mode, int min_disp16, int max_disp16);
 void pose_alt_free(vo_ctx* ctx);
+size_t pose_ws_bytes(int nq);   // pose / clique scratch for nq query keypoints
 
 // implemented in the per-stage files
 int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);

@@ -345,3 +345,77 @@ def test_pose_started_ahead_is_never_reused_for_a_refilled_slot():
             cam.reset_lookahead()
         ok = odo.update(staged[i], None)
         assert ok == want[j][0] and np.array_equal(odo.c_T_w, want[j][1]), (j, i)
+
+
+def test_inflight_lookahead_keypoints_keep_their_own_quotas():
+    """Keypoint extractions already queued on the look-ahead engines must not see the per-level quotas of a
+    later request with another nfeatures (the level table travels by value in every launch): consume the
+    in-flight frames after such a switch and compare with a context that never looks ahead."""
+    c, cam = _rig("C1", max_keypoints=500)
+    frames = c.pairs(0, 10)
+    staged = cam.stage_pairs(frames)
+    a = StereoOdometer(cam, nfeatures=500, preprocessed_frames=True)
+    for i in range(3):
+        assert a.update(staged[i], None)        # frames 3.. are now in flight with 500-feature extractions
+    b = StereoOdometer(cam, nfeatures=300, preprocessed_frames=True)
+    x3, disp, left = cam.compute_3d(staged[3], None, preprocessed=True)
+    k300, _ = b.orb.detectAndCompute(left, b.feature_mask(disp))      # another nfeatures while 4.. are in flight
+    got = []
+    for i in range(4, 10):
+        ok = a.update(staged[i], None)
+        got.append((ok, a.current_kps.xy.copy(), np.asarray(a.current_desc).copy(), a.c_T_w.copy()))
+    c2, cam2 = _rig("C1", max_keypoints=500)
+    cam2.lookahead = 0
+    r = StereoOdometer(cam2, nfeatures=500, preprocessed_frames=True)
+    for i in (0, 1, 2):
+        assert r.update(*frames[i])
+    for j, i in enumerate(range(4, 10)):
+        ok = r.update(*frames[i])
+        assert ok == got[j][0]
+        assert np.array_equal(r.current_kps.xy, got[j][1]) and np.array_equal(np.asarray(r.current_desc), got[j][2]), i
+        assert np.array_equal(r.c_T_w, got[j][3]), i
+    assert 250 <= len(k300) <= 340 and len(got[-1][1]) > 400
+
+
+def test_failed_prefetch_mid_stream_leaves_the_context_usable(monkeypatch):
+    """A look-ahead submission that fails in the middle of a stream -- before the engine is touched (image larger
+    than the context) and INSIDE the engine scope, after its upload was queued (injected with the library's
+    VO_FAULT_PREFETCH test hook) -- must not leave the context pointing at an engine's stream / workspaces: the
+    pairs after it give the poses of a run that never saw a failure."""
+    from openvo_amd import _native
+    c2, cam2 = _rig("C1", max_keypoints=500)
+    frames = c2.pairs(0, 9)
+    kw = dict(preprocessed_frames=True, rigidity_threshold=0.1, outlier_threshold=0.02)
+    ref = StereoOdometer(cam2, **kw)
+    want = [(ref.update(L, R), ref.c_T_w.copy()) for L, R in frames]
+    monkeypatch.setenv("VO_FAULT_PREFETCH", "5")                   # the 5th submission fails after its ingest was enqueued
+    c, cam = _rig("C1", max_keypoints=500)
+    monkeypatch.delenv("VO_FAULT_PREFETCH")
+    odo = StereoOdometer(cam, **kw)
+    big = np.zeros((c.h + 64, c.w + 64), np.uint8)
+    failures = 0
+
+    def submit(pair):
+        nonlocal failures
+        try:
+            return cam.submit(*pair, preprocessed=True)
+        except _native.VoError as e:
+            assert "injected failure" in str(e)
+            failures += 1
+            return cam.submit(*pair, preprocessed=True)            # the same pair again: must work now
+
+    it = iter(frames)
+    queue = [submit(next(it)) for _ in range(3)]
+    got = []
+    for k in range(len(frames)):
+        if k == 2:
+            with pytest.raises(_native.VoError):
+                cam.submit(big, big, preprocessed=True)            # VO_E_CAP before any engine is involved
+        got.append((odo.update(queue.pop(0), None), odo.c_T_w.copy()))
+        nxt = next(it, None)
+        if nxt is not None:
+            queue.append(submit(nxt))
+    assert failures == 1
+    for (a, Ta), (b, Tb) in zip(got, want):
+        assert a == b and np.array_equal(Ta, Tb)
+    assert np.array_equal(cam.stereoSGBM.compute(*frames[3]), cam2.stereoSGBM.compute(*frames[3]))
