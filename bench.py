@@ -23,7 +23,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "10")   # before any HIP runtime starts (see openvo_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")   # before any HIP runtime starts (see openvo_amd/__init__.py)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -34,7 +34,7 @@ enum {
     VO_E_NUMERIC = -5  /* degenerate input (Umeyama: <3 points / colinear) */
 };
 
-#define VO_NUM_SLOTS 10 /* frame slots per context: the odometer keeps prev and current, up to 7 more hold
+#define VO_NUM_SLOTS 28 /* frame slots per context: the odometer keeps prev and current, up to 25 more hold
                            look-ahead pairs (vo_prefetch_*), one is spare */
 
 /* lifetime ------------------------------------------------------------------------- */

@@ -11,7 +11,7 @@ import os as _os
 # main one; the runtime multiplexes streams onto 4 hardware queues by default, which would serialise
 # whichever of them happen to share one.  Must be set before the
 # HIP runtime initialises (a process that has already created a HIP context keeps its own setting).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "10")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from .stereo_camera import StereoCamera
 from .stereo_odometer import StereoOdometer

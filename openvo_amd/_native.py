@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VO355_LIB") or os.path.join(_HERE, "libvo355.so")   # VO355_LIB: A/B another build of the same ABI
 _CSRC = os.path.join(_HERE, "csrc")
 
-VO_NUM_SLOTS = 10
+VO_NUM_SLOTS = 28
 T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose")
 
 # every symbol include/vo355.h declares (checked by tests/test_abi.py)

@@ -1239,7 +1239,12 @@ static int pose_alt_prepare(vo_ctx* ctx, int k)
     vo_ctx::PoseAlt& p = ctx->pose_alt[k];
     if (p.ready) return VO_OK;
     const size_t cap = (size_t)ctx->kp_cap;
-    VO_HIP(ctx, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    if (ctx->tune_prio) {
+        int lo = 0, hi = 0;
+        VO_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        VO_HIP(ctx, hipStreamCreateWithPriority(&p.stream, hipStreamNonBlocking, hi));
+    } else
+        VO_HIP(ctx, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     VO_HIP(ctx, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     VO_HIP(ctx, hipHostMalloc(&p.result, 1024, hipHostMallocDefault));
     VO_HIP(ctx, hipMalloc((void**)&p.m_idx, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.m_dist, cap * 8 + 256));

@@ -962,13 +962,14 @@ static int launch_raster(vo_ctx* ctx, const SgbmGeom& g, const int16_t* Lin, int
     const int R = raster_rows(NP), nbands = div_up(g.H, R);
     const size_t lds = (size_t)(R + 1) * RS_RING * NP * 256 + (size_t)(R + 1) * RS_RING * 16 + (size_t)32 * 4 +
                        (size_t)R * 2 * 4 * g.Dp * 2;
+    if (!ctx->rs_bnd) VO_HIP(ctx, hipMalloc((void**)&ctx->rs_bnd, (ctx->vol_cells * 3 / 8 + 4096) * 8 + 256));   // first use in this workspace
     auto kern = k_sgbm_raster<NP, PAD, REV, HASIN, WTA>;
     static bool attr_set = false;     // per instantiation: allow more than 64 KB of dynamic LDS
     if (!attr_set) {
         VO_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nbands), dim3((R + 2) * 64), lds, ctx->stream, ctx->C, Lin, Sout, ctx->rs_bnd, ctl, g, R, nbands,
+    hipLaunchKernelGGL(kern, dim3(nbands < ctx->tune_raster_wgs ? nbands : ctx->tune_raster_wgs), dim3((R + 2) * 64), lds, ctx->stream, ctx->C, Lin, Sout, ctx->rs_bnd, ctl, g, R, nbands,
                        ctx->ccl_label, ctx->ccl_runlen, ctx->dump);
     VO_CHECK_LAUNCH(ctx);
     return VO_OK;
@@ -1138,6 +1139,15 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
         default: rc = launch_agg<8>(ctx, g, plan, vol); break;
     }
     if (rc) return rc;
+    if (ctx->stream_hi && !ctx->on_hi && ctx->cur_engine >= 0) {
+        // the rest of this pair (post filters, then the ORB chain) is a chain of short latency-bound launches: it
+        // continues on the engine's high-priority stream, behind everything queued so far
+        hipEvent_t hop = ctx->la_hop[ctx->cur_engine];
+        VO_HIP(ctx, hipEventRecord(hop, ctx->stream));
+        VO_HIP(ctx, hipStreamWaitEvent(ctx->stream_hi, hop, 0));
+        std::swap(ctx->stream, ctx->stream_hi);
+        ctx->on_hi = true;
+    }
     {
         StageTimer t(ctx, VO_T_SGBM_POST);
         hipLaunchKernelGGL(k_lr_median3, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, ctx->disp_tmp, ctx->ccl_size, g, d_disp);

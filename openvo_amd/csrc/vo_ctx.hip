@@ -158,7 +158,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     if (const char* e9 = getenv("VO_RASTER")) ctx->tune_raster = atoi(e9) ? 1 : 0;
     // raster scheme: one extra volume (the E direction, or the reverse pass's sum); the line-per-direction
     // scheme stores one volume per direction (grown on demand)
-    ctx->S_vols = ctx->tune_raster ? 1 : 5;
+    ctx->S_vols = (ctx->tune_raster && getenv("VO_RASTER_AFTER") == nullptr) ? 1 : 5;
     DALLOC(ctx->S, ctx->vol_cells * ctx->S_vols);
     DALLOC(ctx->rs_bnd, ctx->vol_cells / 4 + 4096);      // uint64 words: one volume's worth of bytes
     ctx->rs_ctl_words = 2 * (4 + max_h / 4 + 4);
@@ -195,8 +195,17 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     for (int s = 0; s <= VO_NUM_SLOTS; s++) ctx->slots[s].n_kp_host = ctx->slot_words + s;
     if (const char* e3 = getenv("VO_PATH_PF")) { int v = atoi(e3); if (v == 2 || v == 4 || v == 8) ctx->tune_path_pf = v; }
     if (const char* e8 = getenv("VO_ENGINES")) { int v = atoi(e8); if (v >= 1 && v <= vo_ctx::MAX_ENGINES) ctx->n_engines = v; }
+    {
+        // every engine owns a full SGBM workspace (cost volume + up to 8 path volumes): keep all of them within ~96 GB
+        const double per_engine = (double)ctx->vol_cells * 2.0 * 9.5;
+        const int fit = (int)(96e9 / per_engine);
+        if (ctx->n_engines > fit) ctx->n_engines = fit < 2 ? 2 : fit;
+    }
     if (const char* e7 = getenv("VO_FUSE_WTA")) ctx->tune_fuse_wta = atoi(e7) ? 1 : 0;
     if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);
+    if (const char* e11 = getenv("VO_PRIO")) ctx->tune_prio = atoi(e11);
+    if (const char* e12 = getenv("VO_RASTER_AFTER")) ctx->raster_after = atoi(e12);
+    if (const char* e13 = getenv("VO_RASTER_WGS")) { int v = atoi(e13); if (v >= 1 && v <= 4096) ctx->tune_raster_wgs = v; }
     if (const char* e5 = getenv("VO_SWEEP_XT")) { int v = atoi(e5); if (v == 8 || v == 16) ctx->tune_sweep_xt = v; }
     if (const char* e6 = getenv("VO_SWEEP_TY")) { int v = atoi(e6); if (v >= 4 && v <= 4096) ctx->tune_sweep_ty = v; }
     *out = ctx;
@@ -236,6 +245,8 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         if (a.pinned) (void)hipHostFree(a.pinned);
         if (a.h2d_done) (void)hipEventDestroy(a.h2d_done);
         if (ctx->la_stream[k]) (void)hipStreamDestroy(ctx->la_stream[k]);
+        if (ctx->la_stream_hi[k]) { (void)hipStreamSynchronize(ctx->la_stream_hi[k]); (void)hipStreamDestroy(ctx->la_stream_hi[k]); }
+        if (ctx->la_hop[k]) (void)hipEventDestroy(ctx->la_hop[k]);
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -253,8 +264,10 @@ extern "C" int vo_device_name(const vo_ctx* ctx, char* buf, int buflen)
 extern "C" int vo_synchronize(vo_ctx* ctx)
 {
     if (!ctx) return VO_E_ARG;
-    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++)
+    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) {
         if (ctx->la_stream[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream[k]));
+        if (ctx->la_stream_hi[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream_hi[k]));
+    }
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }
@@ -447,6 +460,7 @@ extern "C" int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preproc
 static void engine_swap(vo_ctx* ctx, int engine)
 {
     std::swap(ctx->stream, ctx->la_stream[engine]);
+    std::swap(ctx->stream_hi, ctx->la_stream_hi[engine]);
     std::swap(ctx->stage_in, ctx->la_stage[engine]);
     vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
     std::swap(ctx->orb, a.orb);   // every engine has its own ORB scratch
@@ -465,8 +479,13 @@ static void engine_swap(vo_ctx* ctx, int engine)
 struct EngineScope {
     vo_ctx* ctx;
     int engine;
-    EngineScope(vo_ctx* c, int e) : ctx(c), engine(e) { engine_swap(ctx, engine); }
-    ~EngineScope() { engine_swap(ctx, engine); }
+    EngineScope(vo_ctx* c, int e) : ctx(c), engine(e) { engine_swap(ctx, engine); ctx->cur_engine = engine; }
+    ~EngineScope()
+    {
+        if (ctx->on_hi) { std::swap(ctx->stream, ctx->stream_hi); ctx->on_hi = false; }   // back from the tail's stream
+        ctx->cur_engine = -1;
+        engine_swap(ctx, engine);
+    }
     EngineScope(const EngineScope&) = delete;
     EngineScope& operator=(const EngineScope&) = delete;
 };
@@ -474,7 +493,14 @@ struct EngineScope {
 static int engine_prepare(vo_ctx* ctx, int engine)
 {
     if (!ctx->la_stream[engine]) {
-        VO_HIP(ctx, hipStreamCreateWithFlags(&ctx->la_stream[engine], hipStreamNonBlocking));
+        if (ctx->tune_prio) {
+            int lo = 0, hi = 0;    // numerically lower = higher priority
+            VO_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            VO_HIP(ctx, hipStreamCreateWithPriority(&ctx->la_stream[engine], hipStreamNonBlocking, lo));
+            VO_HIP(ctx, hipStreamCreateWithPriority(&ctx->la_stream_hi[engine], hipStreamNonBlocking, hi));
+            VO_HIP(ctx, hipEventCreateWithFlags(&ctx->la_hop[engine], hipEventDisableTiming));
+        } else
+            VO_HIP(ctx, hipStreamCreateWithFlags(&ctx->la_stream[engine], hipStreamNonBlocking));
         VO_HIP(ctx, hipMalloc((void**)&ctx->la_stage[engine], ctx->stage_bytes * 2 + 256));
         if (orb_ws_alloc(ctx, ctx->ws_alt[engine].orb)) return vo_fail(ctx, VO_E_HIP, "hipMalloc failed (look-ahead ORB workspace)");
     }
@@ -504,6 +530,7 @@ int slot_wait(vo_ctx* ctx, FrameSlot& f)
     if (f.pending) {
         VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, f.ready, 0));
         f.pending = false;
+        if (ctx->inflight > 0) ctx->inflight--;
     }
     return VO_OK;
 }
@@ -549,7 +576,15 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
         }
         if (!rc && ctx->fault_prefetch > 0 && --ctx->fault_prefetch == 0)
             rc = vo_fail(ctx, VO_E_STATE, "injected failure (VO_FAULT_PREFETCH) inside the engine scope");
-        if (!rc) rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
+        if (!rc) {
+            // scheme of this pair: with a deep enough queue in front of it the pair is not waited for soon, and the
+            // raster scheme (less than half the HBM traffic, long dependency chain) serves throughput; near the head of
+            // the queue the line scheme (short chains) serves latency.  Same disparity either way.
+            const int saved = ctx->tune_raster;
+            if (ctx->raster_after >= 0) ctx->tune_raster = ctx->inflight >= ctx->raster_after ? 1 : 0;
+            rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
+            ctx->tune_raster = saved;
+        }
         if (!rc && ctx->la_orb) {
             const int* q = ctx->la_orb_params;
             rc = orb_slot_enqueue(ctx, f, q[0], q[1], q[2], q[3]);
@@ -559,10 +594,14 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
     }
     if (rc) {
         // the slot holds a half-processed pair: nothing in it may be handed out
-        f.kp_pending = false; f.has_pair = false; f.has_disp = false; f.pending = false;
+        f.kp_pending = false; f.has_pair = false; f.has_disp = false;
+        if (f.pending && ctx->inflight > 0) ctx->inflight--;
+        f.pending = false;
         return rc;
     }
-    f.has_pair = true; f.has_disp = true; f.pending = true;
+    f.has_pair = true; f.has_disp = true;
+    if (!f.pending) ctx->inflight++;
+    f.pending = true;
     return VO_OK;
 }
 

@@ -64,8 +64,17 @@ struct vo_ctx {
     // look-ahead engines (vo_prefetch_*): each has its own stream and staging; engine 0 shares the main
     // SGBM workspace, engines 1.. own an alternate one, so several pairs' SGBM can be in flight (one
     // pair's latency-bound kernels overlap another's bandwidth-bound ones)
-    static const int MAX_ENGINES = 6;
+    static const int MAX_ENGINES = 24;
     hipStream_t la_stream[MAX_ENGINES] = {};
+    // VO_PRIO=1: every engine also owns a HIGH-priority stream; the short latency-bound tail of a pair (median + speckle
+    // filter, ORB chain) hops onto it behind the bandwidth-bound volume kernels, which stay on the (low-priority) engine
+    // stream -- the tail's launches are then dispatched ahead of other pairs' queued volume work
+    hipStream_t la_stream_hi[MAX_ENGINES] = {};
+    hipEvent_t la_hop[MAX_ENGINES] = {};
+    hipStream_t stream_hi = nullptr;   // the current engine's high-priority stream (nullptr on the main stream)
+    int cur_engine = -1;
+    bool on_hi = false;
+    int tune_prio = 0;
     uint8_t* la_stage[MAX_ENGINES] = {};
     hipEvent_t sgbm_done = nullptr;  // end of the latest SGBM run in the CURRENT workspace (any stream)
     bool sgbm_done_valid = false;
@@ -88,7 +97,7 @@ struct vo_ctx {
     bool la_orb = false;
     int la_orb_params[4] = {0, 0, 0, 0};
     int32_t* slot_words = nullptr;   // pinned, one word per slot (keypoint counts of pending runs)
-    int n_engines = 6;               // VO_ENGINES
+    int n_engines = 10;              // VO_ENGINES (needs GPU_MAX_HW_QUEUES >= engines + 4: streams sharing a hardware queue serialise)
     int next_engine = 0;
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;
     std::string err;
@@ -195,6 +204,10 @@ struct vo_ctx {
     int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 15;
     int fault_prefetch = 0;         // VO_FAULT_PREFETCH=n (test hook): the n-th look-ahead submission fails inside its engine scope
     int tune_fuse_wta = 1;          // VO_FUSE_WTA: last (top-down vertical) path fused with the WTA
+    int raster_after = -1;          // VO_RASTER_AFTER=n: a look-ahead pair runs the raster scheme when n or more pairs are already
+                                    // in flight (both schemes give the same bits: the choice is pure scheduling); -1 = never
+    int inflight = 0;               // look-ahead pairs submitted and not yet waited for
+    int tune_raster_wgs = 16;       // VO_RASTER_WGS: workgroups of one raster sweep (each takes bands off a ticket counter)
     int tune_raster = 0;            // VO_RASTER=1: W/NW/N/NE (+ WTA) in one raster pass instead of one line sweep per direction
                                     // (6 instead of 14 volume passes, but a W1 + 2H step dependency chain: slower per pair today)
 

@@ -6,6 +6,7 @@ tag=${1:-r01}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=24   # in the shell: under rocprofv3 the runtime starts before python can set it
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 48 --warmup 6 --cpu-pairs 0 > $out/bench_under_rocprof.json 2> $out/stats.err
 echo "stats done"
