@@ -185,6 +185,16 @@ int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, int n
                         float thr, uint32_t seed, double* E9_out, uint8_t* mask_out, int32_t* counts_out,
                         int32_t* best2_out);
 
+/* Monocular front end of BASELINE config 5 (NOT part of the reference): vo_upload_mono puts one image into a slot
+ * (vo_orb_detect_and_compute with mask_mode 0 then extracts its keypoints); vo_mono_pair chains, entirely on the
+ * device and with ONE host synchronisation, Hamming kNN-2 between the two slots' descriptors -> ratio test ->
+ * essential-matrix RANSAC (as vo_ransac_essential) on the surviving correspondences.  counts3 = {matches after the
+ * ratio test, winning hypothesis, its inlier count}; E9_out = the winner; mask_out / q_idx / t_idx (each `cap`
+ * entries, may be NULL): inlier flag, query and train keypoint index of the first counts3[0] entries. */
+int vo_upload_mono(vo_ctx* ctx, int slot, const uint8_t* img, int w, int h, int channels);
+int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4, int iters, float thr, uint32_t seed,
+                 double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx, int cap);
+
 /* RANSAC solvePnP hypothesis scoring (north star; BASELINE config 2 names "ORB+SGBM+PnP") ----------
  * NOT part of the reference either (openVO fits 3-D/3-D, stereo_odometer.py:187-205): defined by this
  * build.  iters hypotheses; each draws 4 correspondences (same hash RNG), solves P3P on three of them in

@@ -28,6 +28,7 @@ SYMBOLS = [
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
     "vo_sgbm_last_geometry", "vo_sgbm_raster_status",
+    "vo_upload_mono", "vo_mono_pair",
     "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_last_error",
     "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
 ]
@@ -111,6 +112,8 @@ def lib():
         L.vo_get_timings.argtypes = [vp, vp, vp, ci]
         L.vo_sgbm_last_geometry.argtypes = [vp, vp, vp]
         L.vo_sgbm_raster_status.argtypes = [vp, vp]
+        L.vo_upload_mono.argtypes = [vp, ci, vp, ci, ci, ci]
+        L.vo_mono_pair.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, vp, vp, vp, vp, vp, ci]
         L.vo_device_count.argtypes = [vp]
         L.vo_mgpu_unique_id.argtypes = [vp]
         L.vo_mgpu_create.argtypes = [ci, ci, ci, vp, vp]
@@ -423,6 +426,33 @@ class Context:
         self._ck(self._lib.vo_ransac_essential(self._h, _p(pts1), _p(pts2), n, _p(K4), int(iters), float(thr), int(seed),
                                                _p(E), _p(mask), _p(counts), _p(best)))
         return dict(E=E.reshape(3, 3), mask=mask, counts=counts, best_iter=int(best[0]), best_count=int(best[1]))
+
+    def upload_mono(self, slot, img):
+        """One image into a slot (monocular front end)."""
+        ch = 3 if img.ndim == 3 else 1
+        img = _c(img, np.uint8)
+        h, w = img.shape[:2]
+        self._ck(self._lib.vo_upload_mono(self._h, slot, _p(img), w, h, ch))
+        return w, h
+
+    def mono_pair(self, slot_a, slot_b, ratio, K4, iters=5000, thr=1.0, seed=4321, want_matches=False):
+        """kNN-2 + ratio + essential-matrix RANSAC between two slots' keypoints, all on the device, one sync.
+        -> dict(E 3x3, matches M, best_iter, best_count[, mask, q, t of length M])."""
+        K4 = _c(np.asarray(K4, np.float64).reshape(4), np.float64)
+        E = np.zeros(9, np.float64)
+        c3 = np.zeros(3, np.int32)
+        cap = self.kp_cap
+        mask = np.zeros(cap, np.uint8) if want_matches else None
+        q = np.zeros(cap, np.int32) if want_matches else None
+        t = np.zeros(cap, np.int32) if want_matches else None
+        self._ck(self._lib.vo_mono_pair(self._h, int(slot_a), int(slot_b), float(ratio), _p(K4), int(iters), float(thr), int(seed) & 0xFFFFFFFF,
+                                        _p(E), _p(c3), _p(mask) if want_matches else None, _p(q) if want_matches else None,
+                                        _p(t) if want_matches else None, cap))
+        out = {"E": E.reshape(3, 3), "matches": int(c3[0]), "best_iter": int(c3[1]), "best_count": int(c3[2])}
+        if want_matches:
+            m = int(c3[0])
+            out.update(mask=mask[:m].copy(), q=q[:m].copy(), t=t[:m].copy())
+        return out
 
     def ransac_pnp(self, pts3d, pts2d, K4, iters=5000, thr=2.0, seed=4321, want_counts=False):
         pts3d, pts2d = _c(pts3d, np.float32).reshape(-1, 3), _c(pts2d, np.float32).reshape(-1, 2)

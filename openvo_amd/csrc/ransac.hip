@@ -94,11 +94,19 @@ __device__ void rs_svd3(const double* A, double* U, double* w, double* Vt)
 
 struct K4 { double fx, fy, cx, cy; };
 
+// n_dev (may be NULL): the number of correspondences when only the device knows it (vo_mono_pair: the ratio test's
+// survivor count); fewer than 8 correspondences give all-zero hypotheses that score no inlier
 __global__ void __launch_bounds__(64) k_ransac_hyp(const float* __restrict__ p1, const float* __restrict__ p2, int n, K4 K,
-                                                   int iters, uint32_t seed, double* __restrict__ E_out, float* __restrict__ F_out)
+                                                   int iters, uint32_t seed, double* __restrict__ E_out, float* __restrict__ F_out,
+                                                   const int* __restrict__ n_dev)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= iters) return;
+    if (n_dev) n = *n_dev;
+    if (n < 8) {
+        for (int k = 0; k < 9; k++) { E_out[(size_t)h * 9 + k] = 0.0; F_out[(size_t)h * 9 + k] = 0.f; }
+        return;
+    }
     int idx[8];
     for (int j = 0; j < 8; j++) {
         uint32_t attempt = 0;
@@ -170,11 +178,13 @@ __device__ __forceinline__ bool sampson_inlier(const float* F, float u1, float v
 
 // one wave per hypothesis
 __global__ void __launch_bounds__(256) k_ransac_score(const float* __restrict__ p1, const float* __restrict__ p2, int n,
-                                                     const float* __restrict__ F_all, int iters, float thr2, int32_t* __restrict__ counts)
+                                                     const float* __restrict__ F_all, int iters, float thr2, int32_t* __restrict__ counts,
+                                                     const int* __restrict__ n_dev)
 {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (h >= iters) return;
+    if (n_dev) n = *n_dev < 8 ? 0 : *n_dev;
     float F[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) F[k] = F_all[(size_t)h * 9 + k];
@@ -210,9 +220,10 @@ __global__ void __launch_bounds__(1024) k_ransac_best(const int32_t* __restrict_
 }
 
 __global__ void k_ransac_mask(const float* __restrict__ p1, const float* __restrict__ p2, int n, const float* __restrict__ F_all,
-                              const int32_t* __restrict__ best, float thr2, uint8_t* __restrict__ mask)
+                              const int32_t* __restrict__ best, float thr2, uint8_t* __restrict__ mask, const int* __restrict__ n_dev)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) { if (i < n && i >= *n_dev) mask[i] = 0; n = *n_dev < 8 ? 0 : *n_dev; }
     if (i >= n) return;
     const float* F = F_all + (size_t)best[0] * 9;
     float Fl[9];
@@ -249,10 +260,10 @@ extern "C" int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* 
     if (rc) return rc;
     const K4 K{ K4v[0], K4v[1], K4v[2], K4v[3] };
     const float thr2 = thr * thr;
-    hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, d_p1, d_p2, n, K, iters, seed, d_E, d_F);
-    hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, d_p1, d_p2, n, d_F, iters, thr2, d_counts);
+    hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, d_p1, d_p2, n, K, iters, seed, d_E, d_F, nullptr);
+    hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, d_p1, d_p2, n, d_F, iters, thr2, d_counts, nullptr);
     hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(1024), 0, ctx->stream, d_counts, iters, d_best);
-    hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_p1, d_p2, n, d_F, d_best, thr2, d_mask);
+    hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_p1, d_p2, n, d_F, d_best, thr2, d_mask, nullptr);
     VO_CHECK_LAUNCH(ctx);
     VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (mask_out && (rc = xfer_d2h(ctx, mask_out, d_mask, (size_t)n))) return rc;
@@ -261,6 +272,78 @@ extern "C" int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* 
     best2_out[0] = ((int32_t*)ctx->pinned)[0];
     best2_out[1] = ((int32_t*)ctx->pinned)[1];
     VO_HIP(ctx, hipMemcpy(E9_out, d_E + (size_t)best2_out[0] * 9, 72, hipMemcpyDeviceToHost));
+    return VO_OK;
+}
+
+// winner's E (9 doubles) gathered on the device so that one flush brings everything home
+__global__ void k_ransac_pick(const double* __restrict__ E_all, const int32_t* __restrict__ best, double* __restrict__ E9)
+{
+    if (threadIdx.x < 9) E9[threadIdx.x] = E_all[(size_t)best[0] * 9 + threadIdx.x];
+}
+
+// Monocular pair step (BASELINE config 5; no reference counterpart): the keypoints and descriptors two slots
+// already hold -> brute-force Hamming kNN-2 -> ratio test + ordered compaction -> essential-matrix RANSAC on the
+// surviving correspondences, every stage on the device, ONE host synchronisation at the end.
+extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4v, int iters, float thr, uint32_t seed,
+                            double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx, int cap)
+{
+    if (!ctx || slot_a < 0 || slot_a >= VO_NUM_SLOTS || slot_b < 0 || slot_b >= VO_NUM_SLOTS || !K4v || !E9_out || !counts3)
+        return vo_fail(ctx, VO_E_ARG, "vo_mono_pair: bad argument");
+    if (iters <= 0 || iters > (1 << 22)) return vo_fail(ctx, VO_E_ARG, "vo_mono_pair: need 0 < iters <= 4194304");
+    FrameSlot& a = ctx->slots[slot_a];
+    FrameSlot& b = ctx->slots[slot_b];
+    if (!a.has_kp || !b.has_kp) return vo_fail(ctx, VO_E_STATE, "vo_mono_pair: both slots need keypoints (vo_orb_detect_and_compute)");
+    counts3[0] = counts3[1] = counts3[2] = 0;
+    for (int k = 0; k < 9; k++) E9_out[k] = 0.0;
+    if (a.n_kp == 0) return VO_OK;
+    if (b.n_kp < 2) return vo_fail(ctx, VO_E_ARG, "train set has fewer than 2 descriptors");
+    if ((mask_out || q_idx || t_idx) && cap < a.n_kp) return vo_fail(ctx, VO_E_CAP, "vo_mono_pair: outputs hold %d entries, %d keypoints", cap, a.n_kp);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    { int rcw = slot_wait(ctx, a); if (!rcw) rcw = slot_wait(ctx, b); if (rcw) return rcw; }
+    const int nq = a.n_kp;
+    const size_t need = (size_t)iters * (72 + 36 + 4) + (size_t)nq + 4096;
+    if (ctx->ransac_ws_bytes < need) {
+        VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->ransac_ws) (void)hipFree(ctx->ransac_ws);
+        ctx->ransac_ws = nullptr; ctx->ransac_ws_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->ransac_ws, need));
+        ctx->ransac_ws_bytes = need;
+    }
+    uint8_t* w = ctx->ransac_ws;
+    double* d_E = (double*)w; w += (size_t)iters * 72;
+    float* d_F = (float*)w; w += (size_t)iters * 36;
+    int32_t* d_counts = (int32_t*)w; w += (size_t)iters * 4;
+    int32_t* d_best = (int32_t*)w; w += 256;
+    double* d_E9 = (double*)w; w += 256;
+    uint8_t* d_mask = w;
+    int rc;
+    {
+        StageTimer t(ctx, VO_T_MATCH);
+        if ((rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->m_idx, ctx->m_dist))) return rc;
+        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(64), 0, ctx->stream, ctx->m_idx, ctx->m_dist, nq, ratio, a.kp_xy, b.kp_xy,
+                           ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, ctx->m_count);
+    }
+    {
+        StageTimer t(ctx, VO_T_POSE);
+        const K4 K{ K4v[0], K4v[1], K4v[2], K4v[3] };
+        const float thr2 = thr * thr;
+        hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, K, iters, seed, d_E, d_F, ctx->m_count);
+        hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, iters, thr2, d_counts, ctx->m_count);
+        hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(1024), 0, ctx->stream, d_counts, iters, d_best);
+        hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, d_best, thr2, d_mask, ctx->m_count);
+        hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, ctx->stream, d_E, d_best, d_E9);
+        VO_CHECK_LAUNCH(ctx);
+    }
+    int32_t* h = (int32_t*)ctx->pinned;         // [0] M, [1..2] best, then E9 at byte 64
+    VO_HIP(ctx, hipMemcpyAsync(h, ctx->m_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(h + 1, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync((uint8_t*)ctx->pinned + 64, d_E9, 72, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask_out && (rc = xfer_d2h(ctx, mask_out, d_mask, (size_t)nq))) return rc;
+    if (q_idx && (rc = xfer_d2h(ctx, q_idx, ctx->mq_idx, (size_t)nq * 4))) return rc;
+    if (t_idx && (rc = xfer_d2h(ctx, t_idx, ctx->mt_idx, (size_t)nq * 4))) return rc;
+    if ((rc = xfer_flush(ctx))) return rc;       // the one synchronisation
+    counts3[0] = h[0]; counts3[1] = h[1]; counts3[2] = h[0] >= 8 ? h[2] : 0;
+    memcpy(E9_out, (uint8_t*)ctx->pinned + 64, 72);
     return VO_OK;
 }
 

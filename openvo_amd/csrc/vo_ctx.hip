@@ -411,6 +411,22 @@ extern "C" int vo_upload_pair(vo_ctx* ctx, int slot, const uint8_t* left, const 
     return VO_OK;
 }
 
+// one image into a slot (monocular front end, BASELINE config 5): same ingest as the left image of a pair
+extern "C" int vo_upload_mono(vo_ctx* ctx, int slot, const uint8_t* img, int w, int h, int channels)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (!img || (channels != 1 && channels != 3)) return vo_fail(ctx, VO_E_ARG, "vo_upload_mono: bad argument");
+    if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context %dx%d", w, h, ctx->max_w, ctx->max_h);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    FrameSlot& f = ctx->slots[slot];
+    if ((rc = slot_wait(ctx, f))) return rc;
+    StageTimer t(ctx, VO_T_UPLOAD);
+    if ((rc = ingest(ctx, 0, img, w, h, channels, 1, f.left, ctx->stage_in))) return rc;
+    f.w = w; f.h = h; f.has_pair = true; f.has_disp = false; f.has_kp = false; f.n_kp = 0; f.kp_pending = false;
+    return VO_OK;
+}
+
 // ---- inputs kept resident in HBM (streaming ingest / benchmarking) -----------------------
 extern "C" int vo_stage_pairs_alloc(vo_ctx* ctx, int n, int w, int h, int channels)
 {

@@ -257,7 +257,9 @@ int xfer_flush(vo_ctx* ctx);
 int slot_wait(vo_ctx* ctx, FrameSlot& f);
 int orb_slot_enqueue(vo_ctx* ctx, FrameSlot& f, int nfeatures, int mask_mode, int min_disp16, int max_disp16);
 void pose_alt_free(vo_ctx* ctx);
-size_t pose_ws_bytes(int nq);   // pose / clique scratch for nq query keypoints
+size_t pose_ws_bytes(int nq);
+__global__ void k_ratio_compact(const int32_t* idx, const int32_t* dist, int nq, double ratio, const float* xy_q, const float* xy_t,
+                                int32_t* q_out, int32_t* t_out, float* xyq_out, float* xyt_out, int32_t* m_out);   // pose / clique scratch for nq query keypoints
 
 // implemented in the per-stage files
 int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);

@@ -165,3 +165,36 @@ def test_raster_scheme_matches_line_scheme(name, mode, monkeypatch):
         assert ctx.sgbm_raster_status() == 0
         ctx.close()
     assert np.array_equal(out["0"], out["1"])
+
+
+def test_c5_mono_pair_device_chain_and_odometer(oracle, c5):
+    """BASELINE config 5 as ONE device-resident step (vo_mono_pair): slot keypoints -> kNN-2 -> ratio -> 5000-hypothesis
+    essential RANSAC with a single host synchronisation; equals the stage-by-stage oracle composition bit for bit
+    (M, winner, inlier count, mask, match indices; E to 1e-12).  Then MonoOdometer on four frames: the recovered
+    rotation and translation direction follow the synthetic ground truth (no openVO oracle exists for this class)."""
+    from openvo_amd.mono import MonoOdometer
+    c, ctx, frames = c5
+    for s, f in enumerate(frames):
+        ctx.upload_mono(s, f)
+        assert ctx.orb_slot_count(s, 8000, 0) > 7000
+    K4 = [c.f, c.f, c.cx, c.cy]
+    got = ctx.mono_pair(0, 1, 0.8, K4, 5000, 1.0, 4321, want_matches=True)
+    ref = [oracle.orb_detect_and_compute(f, None, 8000) for f in frames]
+    ri, rd = oracle.bf_knn2_hamming(ref[0]["desc"], ref[1]["desc"])
+    rq, rt = oracle.ratio_filter(ri, rd, 0.8)
+    rr = oracle.ransac_essential(ref[0]["xy"][rq], ref[1]["xy"][rt], K4, 5000, 1.0, 4321)
+    assert got["matches"] == len(rq) and np.array_equal(got["q"], rq) and np.array_equal(got["t"], rt)
+    assert got["best_iter"] == rr["best_iter"] and got["best_count"] == rr["best_count"]
+    assert np.array_equal(got["mask"], rr["mask"]) and np.allclose(got["E"], rr["E"], rtol=0, atol=1e-12)
+    K = np.array([[c.f, 0, c.cx], [0, c.f, c.cy], [0, 0, 1.0]])
+    odo = MonoOdometer(K, (c.w, c.h), nfeatures=8000, context=ctx)
+    for k in range(4):
+        assert odo.update(c.pair(k)[0]), (k, odo.skip_cause)
+        if k:
+            gt = np.linalg.inv(Corridor.gt_pose(k)) @ Corridor.gt_pose(k - 1)      # frame k-1 -> k, as c_T_w chains it
+            Tk = odo.c_T_w @ np.linalg.inv(prev_c)
+            dirg = gt[:3, 3] / np.linalg.norm(gt[:3, 3])
+            assert np.dot(Tk[:3, 3], dirg) > 0.98                                     # translation direction within ~11 degrees
+            assert np.abs(Tk[:3, :3] - gt[:3, :3]).max() < 0.02
+            assert odo.last["best_count"] > 0.5 * odo.last["matches"]
+        prev_c = odo.c_T_w.copy()
