@@ -739,6 +739,183 @@ __global__ void __launch_bounds__(256) k_sgbm_vwta(const int16_t* __restrict__ C
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// the same fused sweep with 32 lanes per column (two columns per wave): twice the waves -- 1152 columns make 576
+// waves instead of 288 on 1024 SIMDs -- and half the packed registers per lane, i.e. half the instructions on each
+// wave's serial chain (the counters say this sweep is issue-bound on its lone wave per SIMD: VALU busy 61 %, parked
+// 24 %; profiles/r02_occupancy_c2.csv).  The d-1 / d+1 neighbours cross the two 16-lane DPP rows of a column with
+// wave_shr / wave_shl (column edges patched to MAX_COST), the 32-lane minimum closes with one v_permlane16_swap.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t grp32_min_u32(uint32_t v)
+{
+    v = row_min_u32(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // rows (0,1) and (2,3) exchange
+    return min(r[0], r[1]);
+}
+
+template <int NP>
+__device__ __forceinline__ LV<NP> path_step32(const LV<NP>& Cp, const LV<NP>& Lp, uint32_t delta2, uint32_t P1_2, unsigned padreg, int l32)
+{
+    LV<NP> out;
+    uint32_t prev_hi = DPP(MAXC2, Lp.r[NP - 1], 0x138);   // wave_shr:1 -- lane-1's last register
+    uint32_t next_lo = DPP(MAXC2, Lp.r[0], 0x130);        // wave_shl:1 -- lane+1's first register
+    prev_hi = l32 == 0 ? MAXC2 : prev_hi;                 // the column's first / last lane see the MAX_COST sentinels
+    next_lo = l32 == 31 ? MAXC2 : next_lo;
+    uint32_t w[NP + 1];
+    w[0] = __builtin_amdgcn_alignbit(Lp.r[0], prev_hi, 16);
+#pragma unroll
+    for (int k = 1; k < NP; k++) w[k] = __builtin_amdgcn_alignbit(Lp.r[k], Lp.r[k - 1], 16);
+    w[NP] = __builtin_amdgcn_alignbit(next_lo, Lp.r[NP - 1], 16);
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const uint32_t nb = pk_add_sat(pk_min(w[k], w[k + 1]), P1_2);
+        const uint32_t m = pk_min(pk_min(Lp.r[k], delta2), nb);
+        const uint32_t L = pk_sub(pk_add(Cp.r[k], m), delta2);
+        out.r[k] = ((padreg >> k) & 1u) ? MAXC2 : L;
+    }
+    return out;
+}
+
+// wta_core for a 32-lane column group (threshold form of the uniqueness test only)
+template <int NP, bool PAD>
+__device__ __forceinline__ void wta_core32(const LV<NP>& S, const SgbmGeom& g, int lane, int& minS, int& best, bool& grp_viol)
+{
+    const int l32 = lane & 31, d0 = l32 * 2 * NP;
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const int d = d0 + 2 * k;
+        if (!PAD || d < g.D) {
+            const uint32_t k0 = ((S.r[k] & 0xFFFFu) << 8) | (uint32_t)d;
+            const uint32_t k1 = ((S.r[k] >> 16) << 8) | (uint32_t)(d + 1);
+            key = min(key, min(k0, k1));
+        }
+    }
+    key = grp32_min_u32(key);
+    minS = (int)(key >> 8);
+    best = (int)(key & 255u);
+    const int ur100 = 100 - g.ur;
+    const int a = minS * 100;
+    int T = (int)((float)a * __builtin_amdgcn_rcpf((float)ur100));
+    T += (T * ur100 < a);
+    T += (T * ur100 < a);
+    T -= ((T - 1) * ur100 >= a);
+    T -= ((T - 1) * ur100 >= a);
+    const uint32_t T2 = pk_rep(min(T, 32768));
+    const int t = min(max(best + 4 - d0, 0), 31);
+    uint32_t m8 = ((7u << t) >> 5) & ((1u << (2 * NP)) - 1u);
+    if (PAD) {
+        const int npad = min(max(d0 + 2 * NP - g.D, 0), 2 * NP);
+        m8 |= (0xFFFFu << (2 * NP - npad)) & ((1u << (2 * NP)) - 1u);
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * k, 1);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * k + 1, 1);
+        const uint32_t excl = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
+        any |= pk_sub_sat_u(T2, S.r[k]) & ~excl;
+    }
+    const unsigned long long bal = __ballot(any != 0);
+    grp_viol = ((bal >> (lane & 32)) & 0xFFFFFFFFull) != 0ull;
+}
+
+template <int NP, int NV, bool PAD>
+__global__ void __launch_bounds__(256) k_sgbm_vwta32(const int16_t* __restrict__ C, const int16_t* __restrict__ Lbase, size_t vol,
+                                                    SgbmGeom g, int* __restrict__ aux0, int* __restrict__ aux1)
+{
+    extern __shared__ int16_t s_S[];  // [blockDim/32][2][Dp]
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int x1 = wave * 2 + half;
+    if (wave * 2 >= g.W1) return;
+    const bool live = x1 < g.W1;
+    const int xc = live ? x1 : g.W1 - 1;
+    const int d0 = l32 * 2 * NP;
+    unsigned padreg = 0;
+    if (PAD) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
+    }
+    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
+    const size_t stride = (size_t)g.W1 * g.Dp;
+    const uint32_t start = (uint32_t)(xc * g.Dp + d0);
+    int16_t* myS = s_S + (size_t)(threadIdx.x >> 5) * 2 * g.Dp;
+    LV<NP> Lp;
+#pragma unroll
+    for (int k = 0; k < NP; k++) Lp.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;
+    uint32_t delta2 = P2_2;
+    const bool writer = live && l32 == 0;
+    uint32_t aoff = (uint32_t)(x1 + g.minX1);
+    int prec = -1, pbest = 0, par = 0;
+    constexpr int RPS = NP * (NV + 1);
+    constexpr int PF = RPS <= 10 ? 8 : RPS <= 20 ? 6 : RPS <= 32 ? 4 : 3;
+    LV<NP> cbuf[PF], lbuf[PF][NV];
+    const int16_t* rowC = C;
+    const int16_t* rowL = Lbase;
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        if (k < g.H) {
+            cbuf[k] = lv_load_nt<NP>(rowC + start);
+#pragma unroll
+            for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
+            rowC += stride;
+            rowL += stride;
+        }
+    }
+    for (int y0 = 0; y0 < g.H; y0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int y = y0 + k;
+            if (y < g.H) {
+                const LV<NP> Cv = cbuf[k];
+                LV<NP> S = lbuf[k][0];
+#pragma unroll
+                for (int v = 1; v < NV; v++)
+#pragma unroll
+                    for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], lbuf[k][v].r[q]);
+                if (y + PF < g.H) {
+                    cbuf[k] = lv_load_nt<NP>(rowC + start);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
+                    rowC += stride;
+                    rowL += stride;
+                }
+                const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
+                const int16_t* prevS = myS + (par ^ 1) * g.Dp;
+                const uint32_t nb = ((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1];
+                const LV<NP> L = path_step32<NP>(Cv, Lp, delta2, P1_2, padreg, l32);
+                const uint32_t mn = grp32_min_u32(lane_min16<NP>(L));
+                delta2 = pk_add(pk_rep((int)mn), P2_2);
+                Lp = L;
+#pragma unroll
+                for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], L.r[q]);
+                int minS, best;
+                bool viol;
+                wta_core32<NP, PAD>(S, g, lane, minS, best, viol);
+                lv_store<NP>(myS + par * g.Dp + d0, S);
+                if (writer && y > 0) {
+                    aux0[aoff] = prec;
+                    aux1[aoff] = (int)nb;
+                }
+                if (y > 0) aoff += (uint32_t)g.W;
+                prec = viol ? -1 : ((minS << 8) | best);
+                pbest = best;
+                par ^= 1;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
+        const int16_t* prevS = myS + (par ^ 1) * g.Dp;
+        if (writer) {
+            aux0[aoff] = prec;
+            aux1[aoff] = (int)(((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1]);
+        }
+    }
+}
+
 #include "sgbm_raster.inc"
 
 // left-right check of one pixel on the WTA results: disp1 or INVALID
@@ -1044,6 +1221,19 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
         StageTimer t(ctx, VO_T_SGBM_WTA);
         const size_t sh = (size_t)16 * g.Dp * sizeof(int16_t);   // one row of S per 16-lane group (the fused sweep keeps two)
         if (fuse) {
+            if (ctx->tune_vwta32 && NP % 2 == 0) {
+                // 32 lanes per column: Dp / 64 registers per lane, two columns per wave
+                constexpr int NP2 = NP % 2 == 0 ? NP / 2 : 1;
+                const int nw2 = div_up(g.W1, 2);
+                const size_t sh32 = (size_t)8 * 2 * g.Dp * sizeof(int16_t);   // 8 column groups per 256-thread block, two rows of S each
+#define LAUNCH_VWTA32(NV, PAD) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, NV, PAD>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen)
+                if (plan.n_dirs == 4) { if (g.D == g.Dp) LAUNCH_VWTA32(4, false); else LAUNCH_VWTA32(4, true); }
+                else { if (g.D == g.Dp) LAUNCH_VWTA32(7, false); else LAUNCH_VWTA32(7, true); }
+#undef LAUNCH_VWTA32
+                hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
+                VO_CHECK_LAUNCH(ctx);
+                return VO_OK;
+            }
             const int nw = div_up(g.W1, 4);
             // the sweep leaves a two-word record per pixel in ccl_label / ccl_runlen (free until the speckle
             // filter); k_sgbm_fin turns the records into disp1 + the disp2 atomicMin for all pixels in parallel

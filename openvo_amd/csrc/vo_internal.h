@@ -203,6 +203,7 @@ struct vo_ctx {
     // tuning knobs (environment: VO_PATH_PF, VO_SWEEP_XT, VO_SWEEP_TY), read once in vo_create
     int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 15;
     int fault_prefetch = 0;         // VO_FAULT_PREFETCH=n (test hook): the n-th look-ahead submission fails inside its engine scope
+    int tune_vwta32 = 1;            // VO_VWTA32: the fused vertical + WTA sweep with 32 lanes per column (twice the waves)
     int tune_fuse_wta = 1;          // VO_FUSE_WTA: last (top-down vertical) path fused with the WTA
     int raster_after = -1;          // VO_RASTER_AFTER=n: a look-ahead pair runs the raster scheme when n or more pairs are already
                                     // in flight (both schemes give the same bits: the choice is pure scheduling); -1 = never
