@@ -747,9 +747,11 @@ __device__ void pose_clique_wave(int* s_mem, const unsigned long long* __restric
                     key = max(key, ((unsigned)(nc_r[k] * cand + m) << 16) | (unsigned)(0xFFFF - (lane + 64 * k)));
                 }
             }
-            psum = wave_sum_i32_dpp(psum);
-            if (psum == 0) break;
-            const int sel = 0xFFFF - (int)(wave_max_u32(key) & 0xFFFFu);
+            // a candidate exists iff some key carries nc * cand > 0 (nc >= 1: the consistency matrix has a unit diagonal;
+            // cand is 0 or 1: clique members stay compatible), i.e. iff the winning key's value part exceeds m
+            const unsigned kmax = wave_max_u32(key);
+            if ((int)(kmax >> 16) <= m) break;
+            const int sel = 0xFFFF - (int)(kmax & 0xFFFFu);
             const int selk = sel >> 6, sell = sel & 63;
             const bool mine = lane == sell && ((cl >> selk) & 1u);
             if (__ballot(mine) == 0ull) {   // sel not yet in the clique

@@ -354,6 +354,8 @@ __device__ __forceinline__ void orb_fast_select(const LevelsDev& L, const int32_
     if (threadIdx.x == 0) cnt[CNT_A + lvl] = s_n;
 }
 
+__device__ __forceinline__ int wave_sum_i32(int v);
+
 // Harris response (7x7 block) on the unblurred level, candidate i of this block's level
 __device__ __forceinline__ void orb_harris_one(const LevelDev& d, const uint8_t* pimg,
                                                const int32_t* candA_pos, float* candA_resp, int i)
@@ -462,7 +464,32 @@ __global__ void __launch_bounds__(1024) k_orb_select(const LevelsDev L, const ui
     __syncthreads();
     const LevelDev d = L.l[blockIdx.x];
     const int nA = s_n;
-    for (int i = threadIdx.x; i < nA; i += blockDim.x) orb_harris_one(d, pimg, candA_pos, candA_resp, i);
+    // Harris response: one WAVE per candidate, lane = one of the 7x7 pixels (integer sums: the order of the additions does
+    // not matter, the float tail is evaluated once by lane 0 exactly as before)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+        const int dy = lane / 7 - 3, dx = lane % 7 - 3;
+        const int w = d.w;
+        for (int i = wv; i < nA; i += nwv) {
+            const int pos = candA_pos[d.cand_off + i];
+            int a = 0, b = 0, cc = 0;
+            if (lane < 49) {
+                const uint8_t* p = pimg + d.off + pos + dy * w + dx;
+                const int Ix = (p[1] - p[-1]) * 2 + (p[-w + 1] - p[-w - 1]) + (p[w + 1] - p[w - 1]);
+                const int Iy = (p[w] - p[-w]) * 2 + (p[w - 1] - p[-w - 1]) + (p[w + 1] - p[-w + 1]);
+                a = Ix * Ix; b = Iy * Iy; cc = Ix * Iy;
+            }
+            a = wave_sum_i32(a); b = wave_sum_i32(b); cc = wave_sum_i32(cc);
+            if (lane == 0) {
+                const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+                const float scale4 = scale * scale * scale * scale;
+                const float fa = (float)a, fb = (float)b, fc = (float)cc;
+                const float t1 = fa * fb, t2 = fc * fc, sm = fa + fb;
+                const float t4 = (0.04f * sm) * sm;
+                candA_resp[d.cand_off + i] = ((t1 - t2) - t4) * scale4;
+            }
+        }
+    }
     __syncthreads();
     orb_harris_select(L, candA_pos, candA_resp, fin_pos, fin_resp, tmp_pos, tmp_resp, cnt, s_hist, s_prefix, s_mask, s_remaining, s_nf);
 }

@@ -29,6 +29,7 @@
 //   k_lr_median3   left-right consistency check evaluated inside medianBlur(3)
 //   k_ccl_*        filterSpeckles (run-based union-find labelling)
 #include "vo_internal.h"
+#include <stdlib.h>
 #include <type_traits>
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -1131,7 +1132,11 @@ static PathPlan make_plan(const SgbmGeom& g, int mode)
 }
 
 // rows per band (= compute waves per workgroup) of the raster sweep: two waves per SIMD while the ring fits in LDS
-static inline int raster_rows(int NP) { return NP <= 4 ? 8 : 4; }
+static inline int raster_rows(int NP)
+{
+    if (const char* e = getenv("VO_RASTER_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 8) return v; }
+    return NP <= 4 ? 8 : 4;
+}
 
 template <int NP, bool PAD, bool REV, bool HASIN, bool WTA>
 static int launch_raster(vo_ctx* ctx, const SgbmGeom& g, const int16_t* Lin, int16_t* Sout, int* ctl)

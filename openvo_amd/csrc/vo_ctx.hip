@@ -876,8 +876,9 @@ extern "C" int vo_sgbm_raster_status(vo_ctx* ctx, int* error_out)
         VO_HIP(ctx, hipMemcpy(h.data(), ctx->rs_ctl, h.size() * sizeof(int), hipMemcpyDeviceToHost));
         const int half = ctx->rs_ctl_words / 2;
         for (int b = 0; b < 2; b++)
-            fprintf(stderr, "raster ctl %d: ticket %d err %d slow_above %d slow_below %d spins(any slot) %d %d %d\n", b, h[b * half], h[b * half + 1],
-                    h[b * half + 2], h[b * half + 3], h[b * half + 4 + 8], h[b * half + 4 + 90], h[b * half + 4 + 192]);
+            for (int nb : {2, 8, 90, 192})
+                fprintf(stderr, "raster ctl %d (if %d bands): ticket %d err %d slow_above %d slow_below %d spins %d row_clk64 %d wait_clk64 %d\n", b, nb,
+                        h[b * half], h[b * half + 1], h[b * half + 2], h[b * half + 3], h[b * half + 4 + nb], h[b * half + 4 + nb + 1], h[b * half + 4 + nb + 2]);
     }
     return VO_OK;
 }
