@@ -236,7 +236,8 @@ def bench_c5(args):
     c = Corridor("C5")
     iters, nfeat = 5000, 8000
     Kmat = np.array([[c.f, 0, c.cx], [0, c.f, c.cy], [0, 0, 1.0]])
-    odo = MonoOdometer(Kmat, (c.w, c.h), nfeatures=nfeat, ransac_iters=iters, device=device)
+    solver = int(os.environ.get("VO_C5_SOLVER", "5"))
+    odo = MonoOdometer(Kmat, (c.w, c.h), nfeatures=nfeat, ransac_iters=iters, device=device, solver=solver)
     first = group.rank * K_steps
     n_img = min(W + K_steps, 48)                       # the stream wraps around a 48-frame window (0.1 GB of HBM)
     frames = [c.pair(first + k)[0] for k in range(n_img)]
@@ -271,7 +272,7 @@ def bench_c5(args):
                "n_gpus": group.world, "steps": K_steps, "warmup": W, "ms_per_step": round(1e3 * dt / K_steps, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32", "data": "synthetic",
                "config": {"workload": "C5: mono 1920x1080 corridor stream, ORB %d + Hamming kNN-2/ratio + %d-hypothesis essential-matrix RANSAC "
-                                      "(8-point), one host sync per pair" % (nfeat, iters),
+                                      "(%s minimal solver), one host sync per pair" % (nfeat, iters, "five-point" if solver == 5 else "eight-point"),
                           "parallelism": "frame-sharded x%d" % group.world, "inputs": "resident in HBM",
                           "oracle": "none in openVO (no RANSAC, no monocular path): parity vs the build's own CPU restatement only"},
                "roofline": {"bound": "valu", "kernel": "k_bf_knn2 (Hamming kNN) / k_ransac_score (Sampson inlier count)",

@@ -184,16 +184,23 @@ int vo_rodrigues(const double* R9, double* r3);
 int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K4, int iters,
                         float thr, uint32_t seed, double* E9_out, uint8_t* mask_out, int32_t* counts_out,
                         int32_t* best2_out);
+/* Same contract with the five-point minimal solver (Nister 2004; the estimator cv2.findEssentialMat uses):
+ * each hypothesis draws 6 correspondences, 5 give up to 10 essential matrices (float64, 10th-degree polynomial, real
+ * roots isolated between derivative roots and bisected), the 6th picks the one with the smallest Sampson error; a
+ * hypothesis without a real solution scores 0.  n >= 6. */
+int vo_ransac_essential5(vo_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K4, int iters,
+                         float thr, uint32_t seed, double* E9_out, uint8_t* mask_out, int32_t* counts_out,
+                         int32_t* best2_out);
 
 /* Monocular front end of BASELINE config 5 (NOT part of the reference): vo_upload_mono puts one image into a slot
  * (vo_orb_detect_and_compute with mask_mode 0 then extracts its keypoints); vo_mono_pair chains, entirely on the
  * device and with ONE host synchronisation, Hamming kNN-2 between the two slots' descriptors -> ratio test ->
- * essential-matrix RANSAC (as vo_ransac_essential) on the surviving correspondences.  counts3 = {matches after the
+ * essential-matrix RANSAC (solver 8: as vo_ransac_essential, 5: as vo_ransac_essential5) on the survivors.  counts3 = {matches after the
  * ratio test, winning hypothesis, its inlier count}; E9_out = the winner; mask_out / q_idx / t_idx (each `cap`
  * entries, may be NULL): inlier flag, query and train keypoint index of the first counts3[0] entries. */
 int vo_upload_mono(vo_ctx* ctx, int slot, const uint8_t* img, int w, int h, int channels);
 int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4, int iters, float thr, uint32_t seed,
-                 double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx, int cap);
+                 int solver, double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx, int cap);
 
 /* RANSAC solvePnP hypothesis scoring (north star; BASELINE config 2 names "ORB+SGBM+PnP") ----------
  * NOT part of the reference either (openVO fits 3-D/3-D, stereo_odometer.py:187-205): defined by this

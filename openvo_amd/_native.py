@@ -26,7 +26,7 @@ SYMBOLS = [
     "vo_download_left", "vo_download_right", "vo_cvt_bgr2gray", "vo_remap", "vo_reproject_to_3d",
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints", "vo_download_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
-    "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
+    "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_essential5", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
     "vo_sgbm_last_geometry", "vo_sgbm_raster_status",
     "vo_upload_mono", "vo_mono_pair",
     "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_last_error",
@@ -104,6 +104,7 @@ def lib():
         L.vo_pose_pair_begin.argtypes = [vp, ci, ci, cd, ci, cd, cd, vp]
         L.vo_pose_pair_end.argtypes = [vp, ci, vp, vp, vp, vp]
         L.vo_ransac_essential.argtypes = [vp, vp, vp, ci, vp, ci, ctypes.c_float, ctypes.c_uint32, vp, vp, vp, vp]
+        L.vo_ransac_essential5.argtypes = L.vo_ransac_essential.argtypes
         L.vo_ransac_pnp.argtypes = [vp, vp, vp, ci, vp, ci, ctypes.c_float, ctypes.c_uint32, vp, vp, vp, vp]
         L.vo_umeyama.argtypes = [vp, vp, vp, ci, ci, vp, vp]
         L.vo_rigid_clique.argtypes = [vp, vp, vp, ci, cd, vp]
@@ -113,7 +114,7 @@ def lib():
         L.vo_sgbm_last_geometry.argtypes = [vp, vp, vp]
         L.vo_sgbm_raster_status.argtypes = [vp, vp]
         L.vo_upload_mono.argtypes = [vp, ci, vp, ci, ci, ci]
-        L.vo_mono_pair.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, vp, vp, vp, vp, vp, ci]
+        L.vo_mono_pair.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, ci, vp, vp, vp, vp, vp, ci]
         L.vo_device_count.argtypes = [vp]
         L.vo_mgpu_unique_id.argtypes = [vp]
         L.vo_mgpu_create.argtypes = [ci, ci, ci, vp, vp]
@@ -413,7 +414,9 @@ class Context:
         self._ck(self._lib.vo_pose_pair_end(self._h, int(ticket), _p(counts), _p(rc), _p(T1), _p(T2)))
         return counts, rc, T1, T2
 
-    def ransac_essential(self, pts1, pts2, K4, iters=5000, thr=1.0, seed=4321, want_counts=False):
+    def ransac_essential(self, pts1, pts2, K4, iters=5000, thr=1.0, seed=4321, want_counts=False, solver=8):
+        if solver not in (5, 8):
+            raise ValueError("solver is 5 (five-point) or 8 (eight-point)")
         pts1, pts2 = _c(pts1, np.float32).reshape(-1, 2), _c(pts2, np.float32).reshape(-1, 2)
         if len(pts1) != len(pts2):
             raise ValueError("point sets differ in length")
@@ -423,8 +426,8 @@ class Context:
         mask = np.zeros(n, np.uint8)
         counts = np.zeros(iters, np.int32) if want_counts else None
         best = np.zeros(2, np.int32)
-        self._ck(self._lib.vo_ransac_essential(self._h, _p(pts1), _p(pts2), n, _p(K4), int(iters), float(thr), int(seed),
-                                               _p(E), _p(mask), _p(counts), _p(best)))
+        fn = self._lib.vo_ransac_essential5 if solver == 5 else self._lib.vo_ransac_essential
+        self._ck(fn(self._h, _p(pts1), _p(pts2), n, _p(K4), int(iters), float(thr), int(seed), _p(E), _p(mask), _p(counts), _p(best)))
         return dict(E=E.reshape(3, 3), mask=mask, counts=counts, best_iter=int(best[0]), best_count=int(best[1]))
 
     def upload_mono(self, slot, img):
@@ -435,7 +438,7 @@ class Context:
         self._ck(self._lib.vo_upload_mono(self._h, slot, _p(img), w, h, ch))
         return w, h
 
-    def mono_pair(self, slot_a, slot_b, ratio, K4, iters=5000, thr=1.0, seed=4321, want_matches=False):
+    def mono_pair(self, slot_a, slot_b, ratio, K4, iters=5000, thr=1.0, seed=4321, want_matches=False, solver=8):
         """kNN-2 + ratio + essential-matrix RANSAC between two slots' keypoints, all on the device, one sync.
         -> dict(E 3x3, matches M, best_iter, best_count[, mask, q, t of length M])."""
         K4 = _c(np.asarray(K4, np.float64).reshape(4), np.float64)
@@ -446,7 +449,7 @@ class Context:
         q = np.zeros(cap, np.int32) if want_matches else None
         t = np.zeros(cap, np.int32) if want_matches else None
         self._ck(self._lib.vo_mono_pair(self._h, int(slot_a), int(slot_b), float(ratio), _p(K4), int(iters), float(thr), int(seed) & 0xFFFFFFFF,
-                                        _p(E), _p(c3), _p(mask) if want_matches else None, _p(q) if want_matches else None,
+                                        int(solver), _p(E), _p(c3), _p(mask) if want_matches else None, _p(q) if want_matches else None,
                                         _p(t) if want_matches else None, cap))
         out = {"E": E.reshape(3, 3), "matches": int(c3[0]), "best_iter": int(c3[1]), "best_count": int(c3[2])}
         if want_matches:

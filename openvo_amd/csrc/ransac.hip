@@ -96,6 +96,20 @@ struct K4 { double fx, fy, cx, cy; };
 
 // n_dev (may be NULL): the number of correspondences when only the device knows it (vo_mono_pair: the ratio test's
 // survivor count); fewer than 8 correspondences give all-zero hypotheses that score no inlier
+// F = K^-T E K^-1, scaled to max |entry| = 1, rounded to float32
+__device__ void rs_emit(const double* E, const K4& K, int h, double* __restrict__ E_out, float* __restrict__ F_out)
+{
+    const double ifx = 1.0 / K.fx, ify = 1.0 / K.fy;
+    const double Ki[9] = { ifx, 0, -K.cx * ifx, 0, ify, -K.cy * ify, 0, 0, 1 };
+    double T[9], Fd[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double s = 0; for (int k = 0; k < 3; k++) s += E[r * 3 + k] * Ki[k * 3 + c]; T[r * 3 + c] = s; }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double s = 0; for (int k = 0; k < 3; k++) s += Ki[k * 3 + r] * T[k * 3 + c]; Fd[r * 3 + c] = s; }
+    double mx = 0;
+    for (int k = 0; k < 9; k++) if (fabs(Fd[k]) > mx) mx = fabs(Fd[k]);
+    const double sc = mx > 0 ? 1.0 / mx : 1.0;
+    for (int k = 0; k < 9; k++) { E_out[(size_t)h * 9 + k] = E[k]; F_out[(size_t)h * 9 + k] = (float)(Fd[k] * sc); }
+}
+
 __global__ void __launch_bounds__(64) k_ransac_hyp(const float* __restrict__ p1, const float* __restrict__ p2, int n, K4 K,
                                                    int iters, uint32_t seed, double* __restrict__ E_out, float* __restrict__ F_out,
                                                    const int* __restrict__ n_dev)
@@ -152,17 +166,10 @@ __global__ void __launch_bounds__(64) k_ransac_hyp(const float* __restrict__ p1,
     rs_svd3(e0, U, w, Vt);
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) E[r * 3 + c] = U[r * 3 + 0] * Vt[0 * 3 + c] + U[r * 3 + 1] * Vt[1 * 3 + c];
-    // F = K^-T E K^-1, scaled to max |entry| = 1, rounded to float32
-    const double ifx = 1.0 / K.fx, ify = 1.0 / K.fy;
-    const double Ki[9] = { ifx, 0, -K.cx * ifx, 0, ify, -K.cy * ify, 0, 0, 1 };
-    double T[9], Fd[9];
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double s = 0; for (int k = 0; k < 3; k++) s += E[r * 3 + k] * Ki[k * 3 + c]; T[r * 3 + c] = s; }
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double s = 0; for (int k = 0; k < 3; k++) s += Ki[k * 3 + r] * T[k * 3 + c]; Fd[r * 3 + c] = s; }
-    double mx = 0;
-    for (int k = 0; k < 9; k++) if (fabs(Fd[k]) > mx) mx = fabs(Fd[k]);
-    const double sc = mx > 0 ? 1.0 / mx : 1.0;
-    for (int k = 0; k < 9; k++) { E_out[(size_t)h * 9 + k] = E[k]; F_out[(size_t)h * 9 + k] = (float)(Fd[k] * sc); }
+    rs_emit(E, K, h, E_out, F_out);
 }
+
+#include "fivept.inc"
 
 __device__ __forceinline__ bool sampson_inlier(const float* F, float u1, float v1, float u2, float v2, float thr2)
 {
@@ -179,12 +186,12 @@ __device__ __forceinline__ bool sampson_inlier(const float* F, float u1, float v
 // one wave per hypothesis
 __global__ void __launch_bounds__(256) k_ransac_score(const float* __restrict__ p1, const float* __restrict__ p2, int n,
                                                      const float* __restrict__ F_all, int iters, float thr2, int32_t* __restrict__ counts,
-                                                     const int* __restrict__ n_dev)
+                                                     const int* __restrict__ n_dev, int min_n)
 {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (h >= iters) return;
-    if (n_dev) n = *n_dev < 8 ? 0 : *n_dev;
+    if (n_dev) n = *n_dev < min_n ? 0 : *n_dev;
     float F[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) F[k] = F_all[(size_t)h * 9 + k];
@@ -220,10 +227,10 @@ __global__ void __launch_bounds__(1024) k_ransac_best(const int32_t* __restrict_
 }
 
 __global__ void k_ransac_mask(const float* __restrict__ p1, const float* __restrict__ p2, int n, const float* __restrict__ F_all,
-                              const int32_t* __restrict__ best, float thr2, uint8_t* __restrict__ mask, const int* __restrict__ n_dev)
+                              const int32_t* __restrict__ best, float thr2, uint8_t* __restrict__ mask, const int* __restrict__ n_dev, int min_n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_dev) { if (i < n && i >= *n_dev) mask[i] = 0; n = *n_dev < 8 ? 0 : *n_dev; }
+    if (n_dev) { const int m = *n_dev; if (i < n && (i >= m || m < min_n)) mask[i] = 0; n = m < min_n ? 0 : m; }
     if (i >= n) return;
     const float* F = F_all + (size_t)best[0] * 9;
     float Fl[9];
@@ -232,11 +239,13 @@ __global__ void k_ransac_mask(const float* __restrict__ p1, const float* __restr
     mask[i] = sampson_inlier(Fl, a.x, a.y, b.x, b.y, thr2) ? 1 : 0;
 }
 
-extern "C" int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K4v, int iters, float thr,
-                                   uint32_t seed, double* E9_out, uint8_t* mask_out, int32_t* counts_out, int32_t* best2_out)
+static int ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K4v, int iters, float thr,
+                            uint32_t seed, double* E9_out, uint8_t* mask_out, int32_t* counts_out, int32_t* best2_out, int solver)
 {
+    const int min_n = solver == 5 ? 6 : 8;
     if (!ctx || !pts1 || !pts2 || !K4v || !E9_out || !best2_out) return vo_fail(ctx, VO_E_ARG, "vo_ransac_essential: bad argument");
-    if (n < 8 || iters <= 0 || iters > (1 << 22) || n > (1 << 24)) return vo_fail(ctx, VO_E_ARG, "vo_ransac_essential: need n >= 8 and 0 < iters <= 4194304");
+    if (n < min_n || iters <= 0 || iters > (1 << 22) || n > (1 << 24))
+        return vo_fail(ctx, VO_E_ARG, "vo_ransac_essential: need n >= %d and 0 < iters <= 4194304", min_n);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     // workspace: points (2 x n x 8 B), E (iters x 72 B), F (iters x 36 B), counts, mask, best
     const size_t need = (size_t)n * 16 + (size_t)iters * (72 + 36 + 4) + (size_t)n + 4096;
@@ -260,10 +269,13 @@ extern "C" int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* 
     if (rc) return rc;
     const K4 K{ K4v[0], K4v[1], K4v[2], K4v[3] };
     const float thr2 = thr * thr;
-    hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, d_p1, d_p2, n, K, iters, seed, d_E, d_F, nullptr);
-    hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, d_p1, d_p2, n, d_F, iters, thr2, d_counts, nullptr);
+    if (solver == 5)
+        hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, d_p1, d_p2, n, K, iters, seed, d_E, d_F, nullptr);
+    else
+        hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, d_p1, d_p2, n, K, iters, seed, d_E, d_F, nullptr);
+    hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, d_p1, d_p2, n, d_F, iters, thr2, d_counts, nullptr, min_n);
     hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(1024), 0, ctx->stream, d_counts, iters, d_best);
-    hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_p1, d_p2, n, d_F, d_best, thr2, d_mask, nullptr);
+    hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_p1, d_p2, n, d_F, d_best, thr2, d_mask, nullptr, min_n);
     VO_CHECK_LAUNCH(ctx);
     VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (mask_out && (rc = xfer_d2h(ctx, mask_out, d_mask, (size_t)n))) return rc;
@@ -273,6 +285,18 @@ extern "C" int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* 
     best2_out[1] = ((int32_t*)ctx->pinned)[1];
     VO_HIP(ctx, hipMemcpy(E9_out, d_E + (size_t)best2_out[0] * 9, 72, hipMemcpyDeviceToHost));
     return VO_OK;
+}
+
+extern "C" int vo_ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K4v, int iters, float thr,
+                                   uint32_t seed, double* E9_out, uint8_t* mask_out, int32_t* counts_out, int32_t* best2_out)
+{
+    return ransac_essential(ctx, pts1, pts2, n, K4v, iters, thr, seed, E9_out, mask_out, counts_out, best2_out, 8);
+}
+
+extern "C" int vo_ransac_essential5(vo_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K4v, int iters, float thr,
+                                    uint32_t seed, double* E9_out, uint8_t* mask_out, int32_t* counts_out, int32_t* best2_out)
+{
+    return ransac_essential(ctx, pts1, pts2, n, K4v, iters, thr, seed, E9_out, mask_out, counts_out, best2_out, 5);
 }
 
 // winner's E (9 doubles) gathered on the device so that one flush brings everything home
@@ -285,8 +309,10 @@ __global__ void k_ransac_pick(const double* __restrict__ E_all, const int32_t* _
 // already hold -> brute-force Hamming kNN-2 -> ratio test + ordered compaction -> essential-matrix RANSAC on the
 // surviving correspondences, every stage on the device, ONE host synchronisation at the end.
 extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4v, int iters, float thr, uint32_t seed,
-                            double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx, int cap)
+                            int solver, double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx, int cap)
 {
+    if (solver != 5 && solver != 8) return vo_fail(ctx, VO_E_ARG, "vo_mono_pair: solver is 5 (five-point) or 8 (eight-point)");
+    const int min_n = solver == 5 ? 6 : 8;
     if (!ctx || slot_a < 0 || slot_a >= VO_NUM_SLOTS || slot_b < 0 || slot_b >= VO_NUM_SLOTS || !K4v || !E9_out || !counts3)
         return vo_fail(ctx, VO_E_ARG, "vo_mono_pair: bad argument");
     if (iters <= 0 || iters > (1 << 22)) return vo_fail(ctx, VO_E_ARG, "vo_mono_pair: need 0 < iters <= 4194304");
@@ -327,10 +353,13 @@ extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, c
         StageTimer t(ctx, VO_T_POSE);
         const K4 K{ K4v[0], K4v[1], K4v[2], K4v[3] };
         const float thr2 = thr * thr;
-        hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, K, iters, seed, d_E, d_F, ctx->m_count);
-        hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, iters, thr2, d_counts, ctx->m_count);
+        if (solver == 5)
+            hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, K, iters, seed, d_E, d_F, ctx->m_count);
+        else
+            hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, K, iters, seed, d_E, d_F, ctx->m_count);
+        hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, iters, thr2, d_counts, ctx->m_count, min_n);
         hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(1024), 0, ctx->stream, d_counts, iters, d_best);
-        hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, d_best, thr2, d_mask, ctx->m_count);
+        hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, d_best, thr2, d_mask, ctx->m_count, min_n);
         hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, ctx->stream, d_E, d_best, d_E9);
         VO_CHECK_LAUNCH(ctx);
     }
@@ -342,7 +371,7 @@ extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, c
     if (q_idx && (rc = xfer_d2h(ctx, q_idx, ctx->mq_idx, (size_t)nq * 4))) return rc;
     if (t_idx && (rc = xfer_d2h(ctx, t_idx, ctx->mt_idx, (size_t)nq * 4))) return rc;
     if ((rc = xfer_flush(ctx))) return rc;       // the one synchronisation
-    counts3[0] = h[0]; counts3[1] = h[1]; counts3[2] = h[0] >= 8 ? h[2] : 0;
+    counts3[0] = h[0]; counts3[1] = h[1]; counts3[2] = h[0] >= min_n ? h[2] : 0;
     memcpy(E9_out, (uint8_t*)ctx->pinned + 64, 72);
     return VO_OK;
 }

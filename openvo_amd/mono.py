@@ -52,8 +52,12 @@ def recover_pose(E, x1, x2):
 
 class MonoOdometer:
     def __init__(self, K, img_size, nfeatures=8000, match_threshold=0.8, ransac_iters=5000, ransac_threshold=1.0,
-                 min_inliers=30, seed=4321, device=0, context=None):
-        """K: 3x3 intrinsics; img_size = (width, height).  ransac_threshold is the Sampson distance in pixels."""
+                 min_inliers=30, seed=4321, device=0, context=None, solver=5):
+        """K: 3x3 intrinsics; img_size = (width, height).  ransac_threshold is the Sampson distance in pixels.
+        solver: 5 = five-point minimal solver (what cv2.findEssentialMat runs), 8 = eight-point."""
+        if solver not in (5, 8):
+            raise ValueError("solver is 5 or 8")
+        self.solver = int(solver)
         K = np.asarray(K, np.float64)
         self.K, self.K4 = K, [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]
         w, h = int(img_size[0]), int(img_size[1])
@@ -85,10 +89,11 @@ class MonoOdometer:
             self._have_prev, self._slot = True, 1 - cur
             return True
         prev = 1 - cur
-        r = ctx.mono_pair(prev, cur, self.match_threshold, self.K4, self.ransac_iters, self.ransac_threshold, self.seed, want_matches=True)
+        r = ctx.mono_pair(prev, cur, self.match_threshold, self.K4, self.ransac_iters, self.ransac_threshold, self.seed, want_matches=True, solver=self.solver)
         self.last = r
-        if r["matches"] < 8 or r["best_count"] < self.min_inliers:
-            self.skip_cause = "matches" if r["matches"] < 8 else "inliers"
+        need = 6 if self.solver == 5 else 8
+        if r["matches"] < need or r["best_count"] < self.min_inliers:
+            self.skip_cause = "matches" if r["matches"] < need else "inliers"
             return False                 # the previous frame stays the reference
         inl = np.nonzero(r["mask"])[0][:512]                      # a few hundred inliers decide the cheirality vote
         xa = ctx.download_keypoints(prev)["xy"][r["q"][inl]].astype(np.float64)

@@ -8,16 +8,17 @@ import numpy as np
 from . import _native
 
 
-def find_essential_mat(points1, points2, K, iters=5000, threshold=1.0, seed=4321, context=None):
+def find_essential_mat(points1, points2, K, iters=5000, threshold=1.0, seed=4321, context=None, solver=8):
     """points: (n, 2) pixel coordinates of matched keypoints in two views; K: 3x3 intrinsics.
-    Returns (E 3x3 float64, inlier mask uint8 (n,), info dict).  Hypotheses come from 8-point
-    minimal sets (hash RNG, reproducible for a given seed); the winner has the most Sampson inliers
-    (threshold in pixels), ties going to the earliest hypothesis."""
+    Returns (E 3x3 float64, inlier mask uint8 (n,), info dict).  Hypotheses come from 8-point minimal
+    sets (solver=8) or from the five-point minimal solver with a sixth correspondence choosing among
+    its solutions (solver=5) -- hash RNG, reproducible for a given seed; the winner has the most
+    Sampson inliers (threshold in pixels), ties going to the earliest hypothesis."""
     K = np.asarray(K, np.float64)
     own = context is None
     ctx = context or _native.Context(0, 64, 64, 16, 64)
     try:
-        r = ctx.ransac_essential(points1, points2, [K[0, 0], K[1, 1], K[0, 2], K[1, 2]], iters, threshold, seed)
+        r = ctx.ransac_essential(points1, points2, [K[0, 0], K[1, 1], K[0, 2], K[1, 2]], iters, threshold, seed, solver=solver)
     finally:
         if own:
             ctx.close()

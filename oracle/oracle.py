@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libvo_oracle.so")
-_SRC = ["src/sgbm.c", "src/imgproc.c", "src/orb.c", "src/match.c", "src/geom.c", "src/ransac.c", "src/pnp.c", "vo_oracle.h"]
+_SRC = ["src/sgbm.c", "src/imgproc.c", "src/orb.c", "src/match.c", "src/geom.c", "src/ransac.c", "src/fivept.c", "src/pnp.c", "vo_oracle.h"]
 
 
 def build_oracle(force=False):
@@ -230,20 +230,42 @@ def svd3(A):
     return U, w, Vt
 
 
-def ransac_essential(p1, p2, K4, iters=5000, thr=1.0, seed=4321):
-    """-> dict(E 3x3, mask uint8 n, counts int32 iters, best_iter, best_count)"""
+def poly10_roots_unit(c):
+    """real roots inside [-1, 1] of sum c[k] z^k (11 coefficients), increasing -- the five-point solver's root finder"""
+    c = _c(c, np.float64).reshape(11)
+    out = np.zeros(10, np.float64)
+    f = lib().vo_ref_poly10_roots_unit
+    f.argtypes = [ctypes.c_void_p] * 2
+    f.restype = ctypes.c_int
+    return out[:f(_p(c), _p(out))].copy()
+
+
+def essential_5pt(x1, x2):
+    """5 normalised correspondences -> list of candidate essential matrices (<= 10, unit Frobenius norm)"""
+    x1, x2 = _c(x1, np.float64).reshape(5, 2), _c(x2, np.float64).reshape(5, 2)
+    out = np.zeros(90, np.float64)
+    f = lib().vo_ref_essential_5pt
+    f.argtypes = [ctypes.c_void_p] * 3
+    f.restype = ctypes.c_int
+    n = f(_p(x1), _p(x2), _p(out))
+    return [out[9 * k:9 * k + 9].reshape(3, 3).copy() for k in range(n)]
+
+
+def ransac_essential(p1, p2, K4, iters=5000, thr=1.0, seed=4321, solver=8):
+    """-> dict(E 3x3, mask uint8 n, counts int32 iters, best_iter, best_count); solver 8 (eight-point) or 5 (five-point
+    + a sixth correspondence to pick among its solutions)"""
     p1, p2, K4 = _c(p1, np.float32).reshape(-1, 2), _c(p2, np.float32).reshape(-1, 2), _c(K4, np.float64)
     n = len(p1)
     E = np.zeros(9, np.float64)
     mask = np.zeros(n, np.uint8)
     counts = np.zeros(iters, np.int32)
     bi = ctypes.c_int(-1)
-    f = lib().vo_ref_ransac_essential
+    f = lib().vo_ref_ransac_essential5 if solver == 5 else lib().vo_ref_ransac_essential
     f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                   ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     best = f(_p(p1), _p(p2), n, _p(K4), int(iters), float(thr), int(seed), _p(E), _p(mask), _p(counts), ctypes.byref(bi))
     if best < 0:
-        raise ValueError("ransac_essential needs at least 8 correspondences")
+        raise ValueError("ransac_essential needs at least %d correspondences" % (6 if solver == 5 else 8))
     return dict(E=E.reshape(3, 3), mask=mask, counts=counts, best_iter=bi.value, best_count=best)
 
 

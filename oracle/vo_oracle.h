@@ -112,6 +112,15 @@ int vo_ref_sampson_count(const float* F9, const float* p1, const float* p2, int 
 int vo_ref_ransac_essential(const float* p1, const float* p2, int n, const double* K4, int iters, float thr,
                             uint32_t seed, double* E_best9, uint8_t* mask, int32_t* counts, int* best_iter);
 
+/* five-point minimal solver (Nister 2004) and the RANSAC loop around it: x1, x2 = 5 normalised points each; E_out up to
+ * 10 x 9 (unit Frobenius norm); returns the number of real solutions.  The hypothesis takes 6 samples: 5 solve, the 6th picks. */
+int vo_ref_poly10_roots_unit(const double* c11, double* out10);   /* real roots of a degree-10 polynomial in [-1, 1] */
+int vo_ref_essential_5pt(const double* x1_10, const double* x2_10, double* E_out90);
+void vo_ref_ransac_sample6(uint32_t seed, int h, int n, int* idx6);
+void vo_ref_essential_5pt_hyp(const float* p1, const float* p2, const int* idx6, const double* K4, double* E9);
+int vo_ref_ransac_essential5(const float* p1, const float* p2, int n, const double* K4, int iters, float thr,
+                             uint32_t seed, double* E_best9, uint8_t* mask, int32_t* counts, int* best_iter);
+
 /* ---- RANSAC solvePnP hypothesis scoring (north star; no openVO counterpart) -------------------- */
 void vo_ref_ransac_sample4(uint32_t seed, int h, int n, int* idx4);
 /* y: 3 unit bearings, x: 3 points (rows) -> number of poses (<= 4), R (row-major 9 each), t (3 each) */

@@ -178,16 +178,18 @@ def test_c5_mono_pair_device_chain_and_odometer(oracle, c5):
         ctx.upload_mono(s, f)
         assert ctx.orb_slot_count(s, 8000, 0) > 7000
     K4 = [c.f, c.f, c.cx, c.cy]
-    got = ctx.mono_pair(0, 1, 0.8, K4, 5000, 1.0, 4321, want_matches=True)
     ref = [oracle.orb_detect_and_compute(f, None, 8000) for f in frames]
     ri, rd = oracle.bf_knn2_hamming(ref[0]["desc"], ref[1]["desc"])
     rq, rt = oracle.ratio_filter(ri, rd, 0.8)
-    rr = oracle.ransac_essential(ref[0]["xy"][rq], ref[1]["xy"][rt], K4, 5000, 1.0, 4321)
-    assert got["matches"] == len(rq) and np.array_equal(got["q"], rq) and np.array_equal(got["t"], rt)
-    assert got["best_iter"] == rr["best_iter"] and got["best_count"] == rr["best_count"]
-    assert np.array_equal(got["mask"], rr["mask"]) and np.allclose(got["E"], rr["E"], rtol=0, atol=1e-12)
+    for solver in (8, 5):
+        got = ctx.mono_pair(0, 1, 0.8, K4, 5000, 1.0, 4321, want_matches=True, solver=solver)
+        rr = oracle.ransac_essential(ref[0]["xy"][rq], ref[1]["xy"][rt], K4, 5000, 1.0, 4321, solver=solver)
+        assert got["matches"] == len(rq) and np.array_equal(got["q"], rq) and np.array_equal(got["t"], rt)
+        assert got["best_iter"] == rr["best_iter"] and got["best_count"] == rr["best_count"], solver
+        assert np.array_equal(got["mask"], rr["mask"]) and np.allclose(got["E"], rr["E"], rtol=0, atol=1e-12)
     K = np.array([[c.f, 0, c.cx], [0, c.f, c.cy], [0, 0, 1.0]])
-    odo = MonoOdometer(K, (c.w, c.h), nfeatures=8000, context=ctx)
+    odo = MonoOdometer(K, (c.w, c.h), nfeatures=8000, context=ctx)            # five-point solver by default
+    assert odo.solver == 5
     for k in range(4):
         assert odo.update(c.pair(k)[0]), (k, odo.skip_cause)
         if k:

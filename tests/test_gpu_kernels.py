@@ -186,6 +186,36 @@ def test_ransac_essential_bit_exact(oracle, ctx_small, n, iters):
         assert got["mask"][inl].mean() > 0.95 and got["mask"][out].mean() < 0.1
 
 
+@pytest.mark.parametrize("n,iters", [(2000, 500), (6, 16), (8000, 300), (77, 1000), (9, 4096)])
+def test_ransac_five_point_bit_exact(oracle, ctx_small, n, iters):
+    """Five-point solver (no openVO counterpart): one lane per hypothesis on the GPU vs the CPU restatement -- every
+    hypothesis' inlier count (so every root found, every pick made identically), the winner, its mask and E."""
+    p1, p2, K4, R, t, out = _two_view(n, 3 * n + iters)
+    ref = oracle.ransac_essential(p1, p2, K4, iters, 1.0, 4321, solver=5)
+    got = ctx_small.ransac_essential(p1, p2, K4, iters, 1.0, 4321, want_counts=True, solver=5)
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert got["best_iter"] == ref["best_iter"] and got["best_count"] == ref["best_count"]
+    assert np.array_equal(got["mask"], ref["mask"])
+    assert np.allclose(got["E"], ref["E"], rtol=0, atol=1e-12)
+    if n >= 2000:
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Et = tx @ R
+        Et /= np.linalg.norm(Et)
+        E = got["E"] / np.linalg.norm(got["E"])
+        assert min(np.abs(E - Et).max(), np.abs(E + Et).max()) < 0.06
+        inl = np.setdiff1d(np.arange(n), out)
+        assert got["mask"][inl].mean() > 0.95 and got["mask"][out].mean() < 0.1
+
+
+def test_ransac_five_point_argument_checks(ctx_small):
+    from openvo_amd._native import VoError
+    p = np.zeros((5, 2), np.float32)
+    with pytest.raises(VoError):
+        ctx_small.ransac_essential(p, p, [500, 500, 320, 240], 10, 1.0, 1, solver=5)      # needs 6
+    with pytest.raises(ValueError):
+        ctx_small.ransac_essential(p, p, [500, 500, 320, 240], 10, 1.0, 1, solver=7)
+
+
 def _pnp_scene(n, seed, outlier_frac=0.3, noise=0.3):
     rng = np.random.default_rng(seed)
     f, cx, cy = 718.856, 640.0, 360.0
