@@ -651,25 +651,47 @@ struct PoseOut {
 };
 
 // consistency matrix as bit rows: bits[i][w] bit b = | ||cur_i-cur_j|| - ||prev_i-prev_j|| | < thr, j = 64 w + b
-__global__ void k_pose_cons_bits(const float* __restrict__ prev, const float* __restrict__ cur, const int* __restrict__ m_dev,
-                                 float thr, unsigned long long* __restrict__ bits, int words_cap, int* __restrict__ ncons)
+// one 64-lane block per row i of the consistency matrix: the row's bit words (ballots), its popcount, and -- up to 512
+// matches -- one byte per lane holding the row's bits for elements lane + 64 k (what the greedy loop in k_pose_solve reads)
+__global__ void __launch_bounds__(64) k_pose_cons_bits(const float* __restrict__ prev, const float* __restrict__ cur, const int* __restrict__ m_dev,
+                                                       float thr, unsigned long long* __restrict__ bits, int words_cap, int* __restrict__ ncons,
+                                                       uint8_t* __restrict__ lanebytes)
 {
     const int m = *m_dev;
-    const int i = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
-    if (i >= m || blockIdx.x * 64 >= m) return;
-    bool c = false;
-    if (j < m) {
-        float ax = cur[3 * i] - cur[3 * j], ay = cur[3 * i + 1] - cur[3 * j + 1], az = cur[3 * i + 2] - cur[3 * j + 2];
-        float bx = prev[3 * i] - prev[3 * j], by = prev[3 * i + 1] - prev[3 * j + 1], bz = prev[3 * i + 2] - prev[3 * j + 2];
-        float na = sqrtf((ax * ax + ay * ay) + az * az), nb = sqrtf((bx * bx + by * by) + bz * bz);
-        c = fabsf(na - nb) < thr;
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= m) return;
+    const int words = (m + 63) >> 6;
+    const float cix = cur[3 * i], ciy = cur[3 * i + 1], ciz = cur[3 * i + 2];
+    const float pix = prev[3 * i], piy = prev[3 * i + 1], piz = prev[3 * i + 2];
+    unsigned byte = 0;
+    int cnt = 0;
+    for (int k = 0; k < words; k++) {
+        const int j = 64 * k + lane;
+        bool c = false;
+        if (j < m) {
+            float ax = cix - cur[3 * j], ay = ciy - cur[3 * j + 1], az = ciz - cur[3 * j + 2];
+            float bx = pix - prev[3 * j], by = piy - prev[3 * j + 1], bz = piz - prev[3 * j + 2];
+            float na = sqrtf((ax * ax + ay * ay) + az * az), nb = sqrtf((bx * bx + by * by) + bz * bz);
+            c = fabsf(na - nb) < thr;
+        }
+        const unsigned long long bal = __ballot(c);
+        if (lane == 0) bits[(size_t)i * words_cap + k] = bal;
+        cnt += __popcll(bal);
+        byte |= (unsigned)c << (k & 7);
     }
-    const unsigned long long bal = __ballot(c);
-    if (threadIdx.x == 0) {
-        bits[(size_t)i * words_cap + blockIdx.x] = bal;
-        if (bal) atomicAdd(&ncons[i], __popcll(bal));  // row sum == column sum (symmetric matrix)
-    }
+    if (words <= 8) lanebytes[(size_t)i * 64 + lane] = (uint8_t)byte;
+    if (lane == 0) ncons[i] = cnt;
 }
+
+#ifdef VO_POSE_STAMPS
+__device__ long long g_pose_stamps[32];
+#define STAMP(k) do { if (threadIdx.x == 0) g_pose_stamps[k] = (long long)wall_clock64(); } while (0)
+__device__ void g_stamp_aux(int a, int b) { g_pose_stamps[20] = a; g_pose_stamps[21] = b; }
+extern "C" int vo_debug_pose_stamps(long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_pose_stamps), 32 * 8); }
+#else
+#define STAMP(k) do {} while (0)
+__device__ __forceinline__ void g_stamp_aux(int, int) {}
+#endif
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
@@ -689,86 +711,87 @@ __device__ __forceinline__ int wave_sum_i32_dpp(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// float64 wave sum on DPP moves (two per step); every lane of the result is NOT valid -- lane 63 is, and it is broadcast
+__device__ __forceinline__ double wave_sum_f64_dpp(double v)
+{
+#define DPP_ADD64(ctrl, rmask)                                                                             \
+    {                                                                                                      \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false);         \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false);         \
+        v += __hiloint2double(hi, lo);                                                                     \
+    }
+    DPP_ADD64(0x111, 0xf) DPP_ADD64(0x112, 0xf) DPP_ADD64(0x114, 0xf) DPP_ADD64(0x118, 0xf)
+    DPP_ADD64(0x142, 0xa) DPP_ADD64(0x143, 0xc)
+#undef DPP_ADD64
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// register-resident greedy clique (m <= 64 * KREG <= 512), one wave: lane holds elements j = lane + 64 k; the clique and
+// the set of nodes adjacent to every member are K-bit masks per lane.  A node stays in that set exactly when it is
+// adjacent to the member just added, so one byte per (row, lane) -- the row's bits for this lane's K elements, laid out
+// by k_pose_cons_bits -- is all an iteration reads: cp &= lanebits[sel][lane].
+template <int KREG>
+__device__ __forceinline__ void clique_fast(const uint8_t* lanebits, const int* __restrict__ ncons, int m, int lane, int* clique)
+{
+    unsigned keyk[KREG];
+    unsigned vmask = 0, key = 0;
+#pragma unroll
+    for (int k = 0; k < KREG; k++) {
+        const int j = lane + 64 * k;
+        const bool valid = j < m;
+        vmask |= (unsigned)valid << k;
+        keyk[k] = valid ? (((unsigned)(ncons[j] + m) << 16) | (unsigned)(0xFFFF - j)) : 0u;   // most consistent, then lowest index
+        key = max(key, keyk[k]);
+    }
+    const int seed = 0xFFFF - (int)(wave_max_u32(key) & 0xFFFFu);
+    unsigned cp = (unsigned)lanebits[seed * 64 + lane] & vmask;
+    unsigned cl = lane == (seed & 63) ? 1u << (seed >> 6) : 0u;
+    STAMP(10);
+    int csize = 1;
+    for (int it = 0; it < m; it++) {
+        const unsigned cand = cp & ~cl;               // adjacent to every member and not a member (unit diagonal: members stay in cp)
+        unsigned t[KREG];
+#pragma unroll
+        for (int k = 0; k < KREG; k++) t[k] = keyk[k] & (unsigned)__builtin_amdgcn_sbfe((int)cand, k, 1);
+#pragma unroll
+        for (int w = KREG / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int k = 0; k < w; k++) t[k] = max(t[k], t[k + w]);
+        const unsigned kmax = wave_max_u32(t[0]);
+        if (kmax == 0u) break;                        // (a candidate's key is at least (m + 1) << 16)
+        const int sel = 0xFFFF - (int)(kmax & 0xFFFFu);
+        cp &= (unsigned)lanebits[sel * 64 + lane];
+        cl |= lane == (sel & 63) ? 1u << (sel >> 6) : 0u;
+        csize++;
+    }
+    STAMP(11);
+    if (threadIdx.x == 0) g_stamp_aux(csize, m);
+#pragma unroll
+    for (int k = 0; k < KREG; k++)
+        if ((vmask >> k) & 1u) clique[lane + 64 * k] = (int)((cl >> k) & 1u);
+}
+
 // greedy clique on one wave over the bit matrix, then ordered compaction of the kept pairs.
 // 32-bit argmax keys ((value + m) << 16 | (0xFFFF - index)) need m < 32768.
 __device__ void pose_clique_wave(int* s_mem, const unsigned long long* __restrict__ bits, int words_cap,
                                  const int* __restrict__ ncons, const int* __restrict__ m_dev, int use_filter,
                                  const float* __restrict__ pa, const float* __restrict__ pb,
                                  float* __restrict__ qa, float* __restrict__ qb, int* __restrict__ n1_out,
-                                 int lds_m_cap, size_t lds_bits_cap)
+                                 int lds_m_cap, size_t lds_bits_cap, bool fast)
 {
-    // s_mem: 4 * lds_m_cap ints, then lds_bits_cap bytes for the bit matrix; called by ONE wave (threads 0..63)
+    // s_mem: 4 * lds_m_cap ints, then lds_bits_cap bytes for the bit matrix (fast: the per-lane row bytes); called by
+    // ONE wave (threads 0..63)
     const int m = *m_dev;
     int* clique = s_mem;
     int* compat = s_mem + lds_m_cap;
     int* dots = s_mem + 2 * lds_m_cap;
     int* nc = s_mem + 3 * lds_m_cap;
     const int lane = threadIdx.x;
-    constexpr int KREG = 8;
-    const int mw0 = (m + 63) >> 6;
-    if (use_filter && m > 0 && m <= 64 * KREG && lds_bits_cap >= (size_t)m * mw0 * 8) {
-        // register-resident variant (m <= 512): lane holds elements j = lane + 64 k; clique /
-        // compatible sets are K-bit masks, the running dot products live in registers and a row of
-        // the bit matrix is K wave-uniform LDS words.
-        unsigned long long* lb = (unsigned long long*)(s_mem + 4 * lds_m_cap);
-        for (int k = lane; k < m * mw0; k += 64) lb[k] = bits[(size_t)(k / mw0) * words_cap + (k % mw0)];
-        __builtin_amdgcn_wave_barrier();
-        int nc_r[KREG], dots_r[KREG];
-        unsigned cl = 0, cp = 0, vmask = 0;
-        unsigned key = 0;
-#pragma unroll
-        for (int k = 0; k < KREG; k++) {
-            const int j = lane + 64 * k;
-            const bool valid = j < m;
-            vmask |= (unsigned)valid << k;
-            nc_r[k] = valid ? ncons[j] : 0;
-            if (valid) key = max(key, ((unsigned)(nc_r[k] + m) << 16) | (unsigned)(0xFFFF - j));
-        }
-        const int seed = 0xFFFF - (int)(wave_max_u32(key) & 0xFFFFu);
-        {
-            const unsigned long long* row = lb + (size_t)seed * mw0;
-#pragma unroll
-            for (int k = 0; k < KREG; k++) {
-                const int b = ((vmask >> k) & 1u) ? (int)((row[k < mw0 ? k : 0] >> lane) & 1ull) : 0;
-                dots_r[k] = b;
-                cp |= (unsigned)b << k;
-            }
-            if (lane == (seed & 63)) cl = 1u << (seed >> 6);
-        }
-        int csize = 1;
-        for (int it = 0; it < m; it++) {
-            int psum = 0;
-            key = 0;
-#pragma unroll
-            for (int k = 0; k < KREG; k++) {
-                if ((vmask >> k) & 1u) {
-                    const int cand = (int)((cp >> k) & 1u) - (int)((cl >> k) & 1u);
-                    psum += cand;
-                    key = max(key, ((unsigned)(nc_r[k] * cand + m) << 16) | (unsigned)(0xFFFF - (lane + 64 * k)));
-                }
-            }
-            // a candidate exists iff some key carries nc * cand > 0 (nc >= 1: the consistency matrix has a unit diagonal;
-            // cand is 0 or 1: clique members stay compatible), i.e. iff the winning key's value part exceeds m
-            const unsigned kmax = wave_max_u32(key);
-            if ((int)(kmax >> 16) <= m) break;
-            const int sel = 0xFFFF - (int)(kmax & 0xFFFFu);
-            const int selk = sel >> 6, sell = sel & 63;
-            const bool mine = lane == sell && ((cl >> selk) & 1u);
-            if (__ballot(mine) == 0ull) {   // sel not yet in the clique
-                csize++;
-                const unsigned long long* row = lb + (size_t)sel * mw0;
-#pragma unroll
-                for (int k = 0; k < KREG; k++)
-                    if ((vmask >> k) & 1u) dots_r[k] += (int)((row[k < mw0 ? k : 0] >> lane) & 1ull);
-                if (lane == sell) cl |= 1u << selk;
-            }
-            cp = 0;
-#pragma unroll
-            for (int k = 0; k < KREG; k++) cp |= (unsigned)(((vmask >> k) & 1u) && dots_r[k] >= csize) << k;
-        }
-#pragma unroll
-        for (int k = 0; k < KREG; k++)
-            if ((vmask >> k) & 1u) clique[lane + 64 * k] = (int)((cl >> k) & 1u);
+    if (fast) {
+        const uint8_t* lanebits = (const uint8_t*)(s_mem + 4 * lds_m_cap);
+        if (m <= 128) clique_fast<2>(lanebits, ncons, m, lane, clique);
+        else if (m <= 256) clique_fast<4>(lanebits, ncons, m, lane, clique);
+        else clique_fast<8>(lanebits, ncons, m, lane, clique);
         __builtin_amdgcn_wave_barrier();
     } else if (use_filter && m > 0) {
         for (int j = lane; j < m; j += 64) nc[j] = ncons[j];
@@ -836,49 +859,64 @@ __device__ void dev_cross3(const double* a, const double* b, double* c)
 }
 
 // the same one-sided Jacobi SVD as host_svd3, on one device thread
+// one Jacobi rotation of columns P, Q (compile-time indices: G and V stay in registers)
+template <int P, int Q>
+__device__ __forceinline__ bool svd3_rotate(double* G, double* V)
+{
+    double al = 0, be = 0, ga = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        al += G[i * 3 + P] * G[i * 3 + P];
+        be += G[i * 3 + Q] * G[i * 3 + Q];
+        ga += G[i * 3 + P] * G[i * 3 + Q];
+    }
+    if (fabs(ga) <= 1e-300 || fabs(ga) <= 2.2204460492503131e-16 * sqrt(al * be)) return false;
+    const double zeta = (be - al) / (2.0 * ga);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double gp = G[i * 3 + P], gq = G[i * 3 + Q];
+        G[i * 3 + P] = c * gp - s * gq;
+        G[i * 3 + Q] = s * gp + c * gq;
+        const double vp = V[i * 3 + P], vq = V[i * 3 + Q];
+        V[i * 3 + P] = c * vp - s * vq;
+        V[i * 3 + Q] = s * vp + c * vq;
+    }
+    return true;
+}
+__device__ __forceinline__ double pick3(double a, double b, double c, int o) { return o == 0 ? a : (o == 1 ? b : c); }
+
+// one-sided Jacobi SVD of a 3x3 matrix; every index is a compile-time constant or a select, so nothing lives in scratch
 __device__ void dev_svd3(const double* A, double* U, double* w, double* Vt)
 {
     double G[9], V[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+#pragma unroll
     for (int k = 0; k < 9; k++) G[k] = A[k];
     for (int sweep = 0; sweep < 60; sweep++) {
-        bool rotated = false;
-        for (int p = 0; p < 2; p++)
-            for (int q = p + 1; q < 3; q++) {
-                double al = 0, be = 0, ga = 0;
-                for (int i = 0; i < 3; i++) {
-                    al += G[i * 3 + p] * G[i * 3 + p];
-                    be += G[i * 3 + q] * G[i * 3 + q];
-                    ga += G[i * 3 + p] * G[i * 3 + q];
-                }
-                if (fabs(ga) <= 1e-300 || fabs(ga) <= 2.2204460492503131e-16 * sqrt(al * be)) continue;
-                rotated = true;
-                double zeta = (be - al) / (2.0 * ga);
-                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int i = 0; i < 3; i++) {
-                    double gp = G[i * 3 + p], gq = G[i * 3 + q];
-                    G[i * 3 + p] = c * gp - s * gq;
-                    G[i * 3 + q] = s * gp + c * gq;
-                    double vp = V[i * 3 + p], vq = V[i * 3 + q];
-                    V[i * 3 + p] = c * vp - s * vq;
-                    V[i * 3 + q] = s * vp + c * vq;
-                }
-            }
+        bool rotated = svd3_rotate<0, 1>(G, V);
+        rotated |= svd3_rotate<0, 2>(G, V);
+        rotated |= svd3_rotate<1, 2>(G, V);
         if (!rotated) break;
     }
     double sv[3];
-    int ord[3] = { 0, 1, 2 };
+#pragma unroll
     for (int j = 0; j < 3; j++) sv[j] = sqrt(G[j] * G[j] + G[3 + j] * G[3 + j] + G[6 + j] * G[6 + j]);
-    for (int i = 0; i < 2; i++)
-        for (int j = i + 1; j < 3; j++)
-            if (sv[ord[j]] > sv[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    int o0 = 0, o1 = 1, o2 = 2;                    // descending order of the singular values (same swaps as a selection sort)
+    if (pick3(sv[0], sv[1], sv[2], o1) > pick3(sv[0], sv[1], sv[2], o0)) { const int t = o0; o0 = o1; o1 = t; }
+    if (pick3(sv[0], sv[1], sv[2], o2) > pick3(sv[0], sv[1], sv[2], o0)) { const int t = o0; o0 = o2; o2 = t; }
+    if (pick3(sv[0], sv[1], sv[2], o2) > pick3(sv[0], sv[1], sv[2], o1)) { const int t = o1; o1 = o2; o2 = t; }
+    const int ord[3] = { o0, o1, o2 };
     double Uc[3][3], Vc[3][3];
+#pragma unroll
     for (int j = 0; j < 3; j++) {
         const int o = ord[j];
-        w[j] = sv[o];
+        const double svo = pick3(sv[0], sv[1], sv[2], o);
+        w[j] = svo;
+#pragma unroll
         for (int i = 0; i < 3; i++) {
-            Vc[j][i] = V[i * 3 + o];
-            Uc[j][i] = sv[o] > 0 ? G[i * 3 + o] / sv[o] : 0.0;
+            Vc[j][i] = pick3(V[i * 3], V[i * 3 + 1], V[i * 3 + 2], o);
+            Uc[j][i] = svo > 0 ? pick3(G[i * 3], G[i * 3 + 1], G[i * 3 + 2], o) / svo : 0.0;
         }
     }
     const double tiny = w[0] * 1e-300 + 1e-300;
@@ -887,14 +925,20 @@ __device__ void dev_svd3(const double* A, double* U, double* w, double* Vt)
         if (fabs(Uc[0][0]) > 0.9) { a[0] = 0; a[1] = 1; }
         dev_cross3(Uc[0], a, Uc[1]);
         double nn = sqrt(Uc[1][0] * Uc[1][0] + Uc[1][1] * Uc[1][1] + Uc[1][2] * Uc[1][2]);
+#pragma unroll
         for (int i = 0; i < 3; i++) Uc[1][i] /= nn;
     }
     if (w[2] <= tiny || w[2] <= 1e-14 * w[0]) {
         dev_cross3(Uc[0], Uc[1], Uc[2]);
         double nn = sqrt(Uc[2][0] * Uc[2][0] + Uc[2][1] * Uc[2][1] + Uc[2][2] * Uc[2][2]);
-        if (nn > 0) for (int i = 0; i < 3; i++) Uc[2][i] /= nn;
+        if (nn > 0) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) Uc[2][i] /= nn;
+        }
     }
+#pragma unroll
     for (int j = 0; j < 3; j++)
+#pragma unroll
         for (int i = 0; i < 3; i++) { U[i * 3 + j] = Uc[j][i]; Vt[j * 3 + i] = Vc[j][i]; }
 }
 
@@ -902,6 +946,7 @@ __device__ double dev_det3(const double* m)
 {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
 }
+
 
 // block-wide float64 sums of up to NV values per thread; result valid in thread 0's copy via sh
 template <int NV>
@@ -923,27 +968,49 @@ __device__ void dev_umeyama_block(const float* __restrict__ src, const float* __
                                   double* T, double* scale, int* rc, double (*sh)[16])
 {
     if (n < min_n || n < 3) { if (threadIdx.x == 0) *rc = n < 3 ? -1 : 1; return; }   // 1 = not attempted
+    // up to 1024 pairs the sums are one wave's work (DPP reductions, no block barrier); the other waves wait at the end
+    const bool one_wave = n <= 1024;
+    if (one_wave && threadIdx.x >= 64) { __syncthreads(); return; }
+    const int stride = one_wave ? 64 : (int)blockDim.x;
     double a[10];
+#pragma unroll
     for (int c = 0; c < 10; c++) a[c] = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x)
+    for (int i = threadIdx.x; i < n; i += stride)
+#pragma unroll
         for (int c = 0; c < 3; c++) { a[c] += (double)src[3 * i + c]; a[3 + c] += (double)dst[3 * i + c]; }
-    block_sum_f64<6>(a, sh);
+    if (one_wave) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) a[c] = wave_sum_f64_dpp(a[c]);
+    } else
+        block_sum_f64<6>(a, sh);
+    STAMP(12);
     const double inv = 1.0 / n;
     double ms[3], md[3];
+#pragma unroll
     for (int c = 0; c < 3; c++) { ms[c] = a[c] * inv; md[c] = a[3 + c] * inv; }
+#pragma unroll
     for (int c = 0; c < 10; c++) a[c] = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n; i += stride) {
         double s[3], d[3];
+#pragma unroll
         for (int c = 0; c < 3; c++) { s[c] = (double)src[3 * i + c] - ms[c]; d[c] = (double)dst[3 * i + c] - md[c]; }
+#pragma unroll
         for (int r = 0; r < 3; r++)
+#pragma unroll
             for (int c = 0; c < 3; c++) a[r * 3 + c] += d[r] * s[c];
         a[9] += s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
     }
-    block_sum_f64<10>(a, sh);
+    if (one_wave) {
+#pragma unroll
+        for (int c = 0; c < 10; c++) a[c] = wave_sum_f64_dpp(a[c]);
+    } else
+        block_sum_f64<10>(a, sh);
+    STAMP(13);
     if (threadIdx.x == 0) {
         double cov[9], U[9], w[3], Vt[9];
         for (int k = 0; k < 9; k++) cov[k] = a[k] * inv;
         dev_svd3(cov, U, w, Vt);
+        STAMP(14);
         const int nz = (w[0] != 0) + (w[1] != 0) + (w[2] != 0);
         if (nz < 2) { *rc = -2; }
         else {
@@ -972,10 +1039,12 @@ __device__ void dev_umeyama_block(const float* __restrict__ src, const float* __
 // first fit + single-pass outlier rejection [reference :188-197] + final fit [:204], one block.
 // errs: scratch of capacity >= n1 doubles; qa/qb are compacted in place.
 __device__ void pose_fit_block(float* __restrict__ qa, float* __restrict__ qb, double outlier_thr, int min_matches,
-                               double* __restrict__ errs, float* __restrict__ ra, float* __restrict__ rb,
+                               double* errs, float* __restrict__ ra, float* __restrict__ rb,
                                PoseOut* __restrict__ out)
 {
     __shared__ double sh[10][16];
+    __shared__ double s_errs[512];
+    __shared__ int s_rank[512];
     __shared__ double s_T[12], s_scale, s_med;
     __shared__ int s_rc, s_n2, s_nan;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -985,8 +1054,11 @@ __device__ void pose_fit_block(float* __restrict__ qa, float* __restrict__ qb, d
     const float* fb = qb;
     if (tid == 0) { s_rc = 1; s_nan = 0; }
     __syncthreads();
+    if (n1 <= 512) errs = s_errs;        // the O(n^2) rank pass below reads every residual n times: keep them in LDS
     if (outlier_thr > 0 && n1 >= 10) {
+        STAMP(2);
         dev_umeyama_block(qa, qb, n1, 3, s_T, &s_scale, &s_rc, sh);
+        STAMP(3);
         if (tid == 0) { out->rc1 = s_rc; for (int k = 0; k < 12; k++) out->T1[k] = s_T[k]; out->s1 = s_scale; }
         __syncthreads();
         if (s_rc == 0) {
@@ -1002,10 +1074,31 @@ __device__ void pose_fit_block(float* __restrict__ qa, float* __restrict__ qb, d
                 if (e != e) s_nan = 1;
             }
             __syncthreads();
+            STAMP(4);
             // np.median: mean of the two middle order statistics (NaN if any NaN)
             if (tid == 0) s_med = 0;
             __syncthreads();
-            if (!s_nan) {
+            if (!s_nan && n1 <= 512) {
+                // rank of every residual (ties by index): the block splits each residual's comparisons over `parts` threads
+                const int parts = max(1, min(nt / n1, 8)), chunk = (n1 + parts - 1) / parts;
+                for (int i = tid; i < n1; i += nt) s_rank[i] = 0;
+                __syncthreads();
+                if (tid < n1 * parts) {
+                    const int i = tid % n1, part = tid / n1;
+                    const double e = s_errs[i];
+                    const int j1 = min((part + 1) * chunk, n1);
+                    int rank = 0;
+                    for (int j = part * chunk; j < j1; j++) { const double f = s_errs[j]; rank += (f < e) || (f == e && j < i); }
+                    atomicAdd(&s_rank[i], rank);
+                }
+                __syncthreads();
+                const int k_hi = n1 / 2, k_lo = (n1 - 1) / 2;
+                if (tid < n1) {
+                    const double e = s_errs[tid];
+                    if (s_rank[tid] == k_hi) atomicAdd(&s_med, 0.5 * e);
+                    if (s_rank[tid] == k_lo) atomicAdd(&s_med, 0.5 * e);
+                }
+            } else if (!s_nan) {
                 const int k_hi = n1 / 2, k_lo = (n1 - 1) / 2;
                 for (int i = tid; i < n1; i += nt) {
                     const double e = errs[i];
@@ -1016,6 +1109,7 @@ __device__ void pose_fit_block(float* __restrict__ qa, float* __restrict__ qb, d
                 }
             }
             __syncthreads();
+            STAMP(5);
             const double thrv = s_nan ? __builtin_nan("") : outlier_thr + s_med;
             // ordered compaction of errors < threshold into ra/rb
             if (tid == 0) s_n2 = 0;
@@ -1039,6 +1133,7 @@ __device__ void pose_fit_block(float* __restrict__ qa, float* __restrict__ qb, d
             fa = ra; fb = rb;
         }
     }
+    STAMP(6);
     if (tid == 0) { out->n2 = n2; if (s_nan) out->flags |= 2; s_rc = 1; }
     __syncthreads();
     if (n2 >= min_matches) {
@@ -1108,21 +1203,34 @@ __global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* _
                                                      float* __restrict__ qb, int lds_m_cap, size_t lds_bits_cap,
                                                      const int* __restrict__ flags_dev, double outlier_thr, int min_matches,
                                                      double* __restrict__ errs, float* __restrict__ ra, float* __restrict__ rb,
-                                                     PoseOut* __restrict__ out)
+                                                     PoseOut* __restrict__ out, const uint8_t* __restrict__ lanebytes)
 {
-    extern __shared__ int s_mem[];
+    extern __shared__ __attribute__((aligned(16))) int s_mem[];
+    STAMP(0);
+    const int m = *m_dev;
+    const bool fast = use_filter && m > 0 && m <= 512 && lds_bits_cap >= (size_t)m * 64;
+    if (fast) {
+        // lanebits[row][lane] = bit k set when row is consistent with element lane + 64 k (written by k_pose_cons_bits):
+        // into LDS, 16 bytes per thread
+        uint4* dst = (uint4*)(s_mem + 4 * lds_m_cap);
+        const uint4* src = (const uint4*)lanebytes;
+        for (int idx = threadIdx.x; idx < m * 4; idx += blockDim.x) dst[idx] = src[idx];
+    }
+    __syncthreads();
     if (threadIdx.x < 64)
-        pose_clique_wave(s_mem, bits, words_cap, ncons, m_dev, use_filter, pa, pb, qa, qb, &out->n1, lds_m_cap, lds_bits_cap);
+        pose_clique_wave(s_mem, bits, words_cap, ncons, m_dev, use_filter, pa, pb, qa, qb, &out->n1, lds_m_cap, lds_bits_cap, fast);
     if (threadIdx.x == 0) out->flags |= *flags_dev;
+    STAMP(1);
     __syncthreads();
     pose_fit_block(qa, qb, outlier_thr, min_matches, errs, ra, rb, out);
+    STAMP(9);
 }
 
 // enqueue the whole fused step for two slots on ctx->stream with the scratch currently installed in ctx; the
 size_t pose_ws_bytes(int nq)
 {
     const int words = (nq + 63) / 64;
-    return (size_t)nq * words * 8 + (size_t)nq * 4 + (size_t)nq * 12 * 4 + (size_t)nq * 8 + 4096;
+    return (size_t)nq * words * 8 + (size_t)nq * 4 + (size_t)nq * 12 * 4 + (size_t)nq * 8 + (size_t)nq * 64 + 4096;
 }
 
 // PoseOut record is copied to host_out (pinned) at the end.  No host synchronisation.
@@ -1149,7 +1257,8 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
     float* d_qa = (float*)wsp; wsp += (size_t)nq * 12;
     float* d_qb = (float*)wsp; wsp += (size_t)nq * 12;
     float* d_ra = (float*)wsp; wsp += (size_t)nq * 12;
-    float* d_rb = (float*)wsp;
+    float* d_rb = (float*)wsp; wsp += (size_t)nq * 12;
+    uint8_t* d_lanebytes = (uint8_t*)(((uintptr_t)wsp + 15) & ~(uintptr_t)15);
     int* d_m = ctx->m_count;  // k_pose_prep writes the match count M here
     int rc;
     {
@@ -1168,15 +1277,16 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
                            ctx->pts_b, ctx->st_a, ctx->st_b, d_ncons);
         const int use_filter = rigidity_thr > 0;
         if (use_filter)
-            hipLaunchKernelGGL(k_pose_cons_bits, dim3(words, nq), dim3(64), 0, ctx->stream, ctx->pts_a, ctx->pts_b, d_m, (float)rigidity_thr,
-                               d_bits, words, d_ncons);
+            hipLaunchKernelGGL(k_pose_cons_bits, dim3(nq), dim3(64), 0, ctx->stream, ctx->pts_a, ctx->pts_b, d_m, (float)rigidity_thr,
+                               d_bits, words, d_ncons, d_lanebytes);
         // LDS: 4 int arrays of nq (rounded to even so the bit matrix stays 8-byte aligned) + bit matrix if <= 48 KB
         const int m_cap = (nq + 1) & ~1;
         size_t bits_cap = (size_t)nq * words * 8;
-        if ((size_t)m_cap * 16 + bits_cap > 60 * 1024) bits_cap = 0;
+        if (nq <= 512 && bits_cap < (size_t)nq * 64) bits_cap = (size_t)nq * 64;   // one byte per (row, lane): the register-resident greedy loop
+        if ((size_t)m_cap * 16 + bits_cap > 56 * 1024) bits_cap = 0;
         hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(1024), (size_t)m_cap * 16 + bits_cap, ctx->stream, d_bits, words, d_ncons, d_m,
                            use_filter, ctx->pts_a, ctx->pts_b, d_qa, d_qb, m_cap, bits_cap, d_flags, outlier_thr, min_matches, d_errs,
-                           d_ra, d_rb, d_out);
+                           d_ra, d_rb, d_out, d_lanebytes);
         VO_CHECK_LAUNCH(ctx);
         VO_HIP(ctx, hipMemcpyAsync(host_out, d_out, sizeof(PoseOut), hipMemcpyDeviceToHost, ctx->stream));
     }

@@ -388,6 +388,42 @@ __device__ __forceinline__ LV<NP> path_step(const LV<NP>& Cp, const LV<NP>& Lp, 
     return out;
 }
 
+// the same step with the d-1 / d+1 windows shared between neighbouring registers: window j = (L[2j-1], L[2j]);
+// LPL = lanes per scan line (16: a DPP row; 8: half a row, the group's first / last lane take the sentinels explicitly)
+template <int NP, bool PAD, int LPL = 16>
+__device__ __forceinline__ LV<NP> path_step2(const LV<NP>& Cp, const LV<NP>& Lp, uint32_t delta2, uint32_t P1_2, unsigned padreg, int l = 0)
+{
+    LV<NP> out;
+    uint32_t prev_hi = DPP(MAXC2, Lp.r[NP - 1], ROW_SHR1);
+    uint32_t next_lo = DPP(MAXC2, Lp.r[0], ROW_SHL1);
+    if constexpr (LPL == 8) {
+        prev_hi = l == 0 ? MAXC2 : prev_hi;
+        next_lo = l == 7 ? MAXC2 : next_lo;
+    }
+    uint32_t w[NP + 1];
+    w[0] = __builtin_amdgcn_alignbit(Lp.r[0], prev_hi, 16);
+#pragma unroll
+    for (int k = 1; k < NP; k++) w[k] = __builtin_amdgcn_alignbit(Lp.r[k], Lp.r[k - 1], 16);
+    w[NP] = __builtin_amdgcn_alignbit(next_lo, Lp.r[NP - 1], 16);
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const uint32_t nb = pk_add_sat(pk_min(w[k], w[k + 1]), P1_2);     // min(a,b)+P1 = min(a+P1, b+P1) under saturation
+        const uint32_t m = pk_min(pk_min(Lp.r[k], delta2), nb);
+        const uint32_t L = pk_sub(pk_add(Cp.r[k], m), delta2);
+        out.r[k] = (PAD && ((padreg >> k) & 1u)) ? MAXC2 : L;
+    }
+    return out;
+}
+
+// all-reduce (min, unsigned) inside each group of 8 lanes
+__device__ __forceinline__ uint32_t half_min_u32(uint32_t v)
+{
+    v = min(v, DPP(0xFFFFFFFFu, v, 0xB1));    // quad_perm [1,0,3,2]
+    v = min(v, DPP(0xFFFFFFFFu, v, 0x4E));    // quad_perm [2,3,0,1]
+    v = min(v, DPP(0xFFFFFFFFu, v, 0x141));   // row_half_mirror
+    return v;
+}
+
 template <int NP>
 __device__ __forceinline__ uint32_t lane_min16(const LV<NP>& v)
 {
@@ -402,20 +438,25 @@ struct PathPlan {
     int n_dirs;
     int sx[VO_MAX_DIRS], sy[VO_MAX_DIRS];
     int nlines[VO_MAX_DIRS];
-    int first_wave[VO_MAX_DIRS + 1];  // prefix sum of ceil(nlines/4)
+    int first_wave[VO_MAX_DIRS + 1];  // prefix sum of ceil(nlines / lines per wave)
+    int lpw;                          // lines per wave (host side: 4 = 16 lanes per line, 8 = 8 lanes per line)
 };
 
-template <int NP, int PF>
+// NP = registers per lane (2*NP disparities), LPL = lanes per scan line (LPL * 2 * NP = Dp), 64 / LPL lines per wave.
+// Fewer lanes per line = more disparities per lane: the per-step fixed work (addresses, the min all-reduce, delta) is
+// spread over more cells and the launch has half the waves.
+template <int NP, int PF, int LPL = 16, bool PAD = true>
 __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ C, int16_t* __restrict__ Lbase, size_t vol,
                                                    SgbmGeom g, PathPlan plan, int16_t* __restrict__ dump)
 {
-    const int lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
+    constexpr int LPW = 64 / LPL;
+    const int lane = threadIdx.x & 63, row = lane / LPL, l16 = lane % LPL;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wave >= plan.first_wave[plan.n_dirs]) return;
     int dir = 0;
     while (dir + 1 < plan.n_dirs && wave >= plan.first_wave[dir + 1]) dir++;
     const int sx = plan.sx[dir], sy = plan.sy[dir];
-    const int line = (wave - plan.first_wave[dir]) * 4 + row;
+    const int line = (wave - plan.first_wave[dir]) * LPW + row;
     const int W1 = g.W1, H = g.H;
     int x0 = 0, y0 = 0, n = 0;
     if (line < plan.nlines[dir]) {
@@ -430,13 +471,16 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
         const int ny = sy > 0 ? H - y0 : (sy < 0 ? y0 + 1 : 1 << 30);
         n = min(nx, ny);
     }
-    int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
-                   max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
+    int nmax = 0;
+#pragma unroll
+    for (int r = 0; r < LPW; r++) nmax = max(nmax, __builtin_amdgcn_readlane(n, r * LPL));
 
     const int d0 = l16 * 2 * NP;
     unsigned padreg = 0;
+    if constexpr (PAD) {
 #pragma unroll
-    for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
+        for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
+    }
     const uint32_t P1_2 = pk_rep(g.P1);
     const uint32_t P2_2 = pk_rep(g.P2);
     const ptrdiff_t stride = ((ptrdiff_t)sy * W1 + sx) * g.Dp;
@@ -469,8 +513,9 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
             const LV<NP> Cv = cbuf[k];
             cbuf[k] = lv_load<NP>(pld);
             pld += (i + PF < last) ? stride : 0;
-            const LV<NP> L = path_step<NP>(Cv, Lp, delta2, P1_2, padreg);
-            const uint32_t mn = row_min_u32(lane_min16<NP>(L));
+            const LV<NP> L = path_step2<NP, PAD, LPL>(Cv, Lp, delta2, P1_2, padreg, l16);
+            const uint32_t lm = lane_min16<NP>(L);
+            const uint32_t mn = LPL == 8 ? half_min_u32(lm) : row_min_u32(lm);
             delta2 = pk_add(pk_rep((int)mn), P2_2);
             Lp = L;
             lv_store_nt<NP>(i < n ? pst : sink, L);
@@ -1112,20 +1157,21 @@ __global__ void k_ccl_apply(int16_t* __restrict__ img, int n, int newVal, int ma
 // ---------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------
-static PathPlan make_plan(const SgbmGeom& g, int mode)
+static PathPlan make_plan(const SgbmGeom& g, int mode, int lpw)
 {
     // steps = negated predecessor offsets.  MODE_SGBM predecessors: (x-1,y) (x+1,y) (x-1,y-1) (x,y-1)
     // (x+1,y-1); MODE_HH adds (x-1,y+1) (x,y+1) (x+1,y+1).  Longest lines first.
     static const int sx5[] = { 1, -1, 1, -1, 0 }, sy5[] = { 0, 0, 1, 1, 1 };
     static const int sx8[] = { 1, -1, 1, -1, 1, -1, 0, 0 }, sy8[] = { 0, 0, 1, 1, -1, -1, -1, 1 };   // (0,+1) last: fused with the WTA
     PathPlan p;
+    p.lpw = lpw;
     p.n_dirs = mode == 1 ? 8 : 5;
     p.first_wave[0] = 0;
     for (int k = 0; k < p.n_dirs; k++) {
         p.sx[k] = mode == 1 ? sx8[k] : sx5[k];
         p.sy[k] = mode == 1 ? sy8[k] : sy5[k];
         p.nlines[k] = p.sy[k] == 0 ? g.H : (p.sx[k] == 0 ? g.W1 : g.W1 + g.H - 1);
-        p.first_wave[k + 1] = p.first_wave[k] + div_up(p.nlines[k], 4);
+        p.first_wave[k + 1] = p.first_wave[k] + div_up(p.nlines[k], lpw);
     }
     for (int k = p.n_dirs; k < VO_MAX_DIRS; k++) { p.sx[k] = p.sy[k] = p.nlines[k] = 0; p.first_wave[k + 1] = p.first_wave[p.n_dirs]; }
     return p;
@@ -1214,12 +1260,21 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
     {
         StageTimer t(ctx, VO_T_SGBM_AGG);
         const int nwaves = plan.first_wave[plan.n_dirs];
-        if (ctx->tune_path_pf == 8 && NP <= 4)
-            hipLaunchKernelGGL((k_sgbm_paths<NP, 8>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump);
-        else if (ctx->tune_path_pf == 2)
-            hipLaunchKernelGGL((k_sgbm_paths<NP, 2>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump);
-        else
-            hipLaunchKernelGGL((k_sgbm_paths<NP, 4>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump);
+        const bool pad = g.D != g.Dp;
+#define LAUNCH_PATHS(NPL, PF, LPL, PAD) hipLaunchKernelGGL((k_sgbm_paths<NPL, PF, LPL, PAD>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump)
+        bool done = false;
+        if constexpr (NP <= 4) {
+            if (plan.lpw == 8) {
+                done = true;
+                if (ctx->tune_path_pf == 8) { if (pad) LAUNCH_PATHS(2 * NP, 8, 8, true); else LAUNCH_PATHS(2 * NP, 8, 8, false); }
+                else { if (pad) LAUNCH_PATHS(2 * NP, 4, 8, true); else LAUNCH_PATHS(2 * NP, 4, 8, false); }
+            }
+        }
+        if (done) {
+        } else if (ctx->tune_path_pf == 8 && NP <= 4) { if (pad) LAUNCH_PATHS(NP, 8, 16, true); else LAUNCH_PATHS(NP, 8, 16, false); }
+        else if (ctx->tune_path_pf == 2) { if (pad) LAUNCH_PATHS(NP, 2, 16, true); else LAUNCH_PATHS(NP, 2, 16, false); }
+        else { if (pad) LAUNCH_PATHS(NP, 4, 16, true); else LAUNCH_PATHS(NP, 4, 16, false); }
+#undef LAUNCH_PATHS
         VO_CHECK_LAUNCH(ctx);
     }
     {
@@ -1296,7 +1351,9 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
     const size_t vol = (size_t)g.W1 * h * g.Dp;
     if (vol > ctx->vol_cells || e.D > 256)
         return vo_fail(ctx, VO_E_CAP, "cost volume %zu cells exceeds the capacity given to vo_create (or D > 256)", vol);
-    const PathPlan plan = make_plan(g, e.mode);
+    // 8 lanes per scan line (16 disparities per lane) up to D = 128 in the line scheme; 16 lanes per line otherwise
+    const bool lanes8 = ctx->tune_path_lanes == 8 && g.Dp <= 128 && !(ctx->tune_raster && ctx->tune_fuse_wta && g.ur < 100);
+    const PathPlan plan = make_plan(g, e.mode, lanes8 ? 8 : 4);
     ctx->last_cells = (int64_t)g.W1 * h * g.D;
     ctx->last_paths = (ctx->tune_fuse_wta && g.ur < 100) ? plan.n_dirs - 1 : plan.n_dirs;   // directions inside the k_sgbm_paths launch
     {

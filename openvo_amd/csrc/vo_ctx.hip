@@ -203,6 +203,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     }
     if (const char* e7 = getenv("VO_FUSE_WTA")) ctx->tune_fuse_wta = atoi(e7) ? 1 : 0;
     if (const char* e14 = getenv("VO_VWTA32")) ctx->tune_vwta32 = atoi(e14) ? 1 : 0;
+    if (const char* e15 = getenv("VO_PATH_LANES")) ctx->tune_path_lanes = atoi(e15) == 8 ? 8 : 16;
     if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);
     if (const char* e11 = getenv("VO_PRIO")) ctx->tune_prio = atoi(e11);
     if (const char* e12 = getenv("VO_RASTER_AFTER")) ctx->raster_after = atoi(e12);
