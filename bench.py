@@ -119,8 +119,12 @@ def main():
     tm = ctx.timings(reset=True)
     raster_err = ctx.sgbm_raster_status()
 
-    tb, nb, from_host_rate = None, 0, None
+    tb, nb, from_host_rate, copy_gbs = None, 0, None, None
     if not args.no_post:
+        # the box's own streaming-copy ceiling: one cost volume's worth of bytes copied between two of the
+        # context's volumes, plain and non-temporal, HIP events around 20 repetitions -- untimed, after the measured region
+        ctx.synchronize()
+        copy_gbs = {"plain": round(ctx.measure_copy(0, 20, False), 1), "nontemporal": round(ctx.measure_copy(0, 20, True), 1)}
         # per-stage breakdown (information only): a short untimed post-pass with every stage timed and the
         # look-ahead engines off, i.e. one pair at a time with each kernel alone on the GPU -- the same
         # condition a rocprofv3 kernel trace imposes (it serialises dispatches)
@@ -181,6 +185,20 @@ def main():
                 "aggregate": {"algorithmic_bytes_per_pair": survey_bytes,
                               "achieved": round(survey_bytes * value / world / 1e9, 2),
                               "frac": round(survey_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)}}
+        if copy_gbs is not None:
+            ceil = max(copy_gbs.values())
+            roof["copy_ceiling"] = {"unit": "GB/s", "bytes_counted": "read + written", **copy_gbs,
+                                    "frac_of_peak": round(ceil / HBM_PEAK_GBS, 4)}
+            if traffic is not None and ceil > 0:
+                # what the path kernels really move per pair (PMC, profiles/traffic_*.json) x pairs/s against that ceiling
+                try:
+                    per_pair = json.load(open(tf))["sgbm_bytes_per_pair"]["line"]["bytes_per_pair_corrected"]
+                except Exception:
+                    per_pair = None
+                if per_pair:
+                    roof["aggregate"]["measured_traffic_bytes_per_pair"] = per_pair
+                    roof["aggregate"]["measured_traffic_gb_per_s"] = round(per_pair * value / world / 1e9, 1)
+                    roof["aggregate"]["measured_traffic_frac_of_copy_ceiling"] = round(per_pair * value / world / 1e9 / ceil, 4)
         if tb is not None:
             iso_ms, iso_n = tb["sgbm_agg"]
             iso_s = (iso_ms / 1e3) / max(iso_n, 1)

@@ -227,6 +227,10 @@ int vo_get_timings(vo_ctx* ctx, double* ms_out /*VO_T_NSTAGES*/, int64_t* launch
  * directions aggregated inside its k_sgbm_paths launch (the remaining top-down vertical direction
  * runs fused with the WTA) */
 int vo_sgbm_last_geometry(vo_ctx* ctx, int64_t* cells, int* n_paths);
+/* measurement aid (SURVEY 8(d) "device-copy ceiling"): `reps` streaming copies of `bytes` (<= one cost volume; 0 = a
+ * whole one) between two of the context's volumes, timed with HIP events; *gb_per_s counts bytes read + bytes written.
+ * Overwrites the cost volume: call it between, not inside, vo_sgbm_compute / vo_prefetch_pair sequences. */
+int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemporal, double* gb_per_s);
 /* health of the raster aggregation sweeps (synchronises): *error_out != 0 when a wait between rows / bands
  * ever exceeded its poll limit (the affected disparities are then undefined); sticky until vo_destroy */
 int vo_sgbm_raster_status(vo_ctx* ctx, int* error_out);

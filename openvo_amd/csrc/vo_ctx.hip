@@ -884,6 +884,50 @@ extern "C" int vo_sgbm_raster_status(vo_ctx* ctx, int* error_out)
     return VO_OK;
 }
 
+// ---- the box's streaming-copy ceiling (the HBM roofline is reported against the 8 TB/s peak and against
+// what a plain device copy reaches on this very GPU) -------------------------------------------------------------
+typedef uint32_t copy_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ void __launch_bounds__(256) k_copy_stream(const copy_u32x4* __restrict__ src, copy_u32x4* __restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+        else dst[i] = src[i];
+    }
+}
+
+extern "C" int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemporal, double* gb_per_s)
+{
+    if (!ctx || !gb_per_s || reps <= 0) return vo_fail(ctx, VO_E_ARG, "vo_measure_copy: bad argument");
+    // source = the first path volume, destination = the cost volume: both exist, neither holds anything a later call needs
+    const int64_t cap = (int64_t)ctx->vol_cells * 2;
+    if (bytes <= 0 || bytes > cap) bytes = cap;
+    bytes &= ~(int64_t)4095;
+    if (bytes <= 0 || !ctx->C || !ctx->S) return vo_fail(ctx, VO_E_STATE, "vo_measure_copy: no volumes to copy between");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    VO_HIP(ctx, hipEventCreate(&e0));
+    VO_HIP(ctx, hipEventCreate(&e1));
+    const size_t n16 = (size_t)bytes / 16;
+    const int blocks = 256 * 16;                           // 16 workgroups per CU, grid-stride
+    auto launch = [&]() {
+        if (nontemporal) hipLaunchKernelGGL(k_copy_stream<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const copy_u32x4*)ctx->S, (copy_u32x4*)ctx->C, n16);
+        else hipLaunchKernelGGL(k_copy_stream<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const copy_u32x4*)ctx->S, (copy_u32x4*)ctx->C, n16);
+    };
+    launch();                                               // warm-up (page tables, clocks)
+    VO_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; r++) launch();
+    VO_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    VO_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    VO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gb_per_s = ms > 0.f ? 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;   // bytes read + bytes written
+    return VO_OK;
+}
+
 extern "C" int vo_sgbm_last_geometry(vo_ctx* ctx, int64_t* cells, int* n_paths)
 {
     if (!ctx) return VO_E_ARG;

@@ -201,7 +201,7 @@ struct vo_ctx {
     int staged_n = 0, staged_w = 0, staged_h = 0, staged_ch = 1;
 
     // tuning knobs (environment: VO_PATH_PF, VO_SWEEP_XT, VO_SWEEP_TY), read once in vo_create
-    int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 15;
+    int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 30;
     int tune_path_lanes = 16;       // VO_PATH_LANES: lanes per scan line in k_sgbm_paths (8 = 16 disparities per lane, D <= 128)
     int fault_prefetch = 0;         // VO_FAULT_PREFETCH=n (test hook): the n-th look-ahead submission fails inside its engine scope
     int tune_vwta32 = 1;            // VO_VWTA32: the fused vertical + WTA sweep with 32 lanes per column (twice the waves)

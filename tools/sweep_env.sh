@@ -1,6 +1,9 @@
 #!/bin/bash
-# usage: tools/sweep_env.sh "VAR1=a VAR2=b" "VAR1=c" ...   -> bench value per environment (same box, back to back)
-for cfg in "$@"; do
-  v=$(env $cfg python bench.py --steps ${SWEEP_STEPS:-300} --warmup 20 --cpu-pairs 0 --no-events 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'])")
-  echo "$cfg -> $v"
+# usage: tools/sweep_env.sh "<steps> <warmup>" VAR "v1 v2 ..." [ENV=VAL ...]  -- bench value per setting of VAR
+spec=$1; var=$2; vals=$3; shift 3
+set -- $spec "$@"; k=$1; w=$2; shift 2
+mkdir -p gpurun_out
+for v in $vals; do
+  env "$@" $var=$v timeout -k 10 200 python bench.py --steps $k --warmup $w --cpu-pairs 0 --no-post > gpurun_out/sw.json 2> gpurun_out/sw.err || { echo "$var=$v failed"; tail -2 gpurun_out/sw.err; continue; }
+  python -c "import json;d=json.load(open('gpurun_out/sw.json'));print('$* $var=$v steps=$k value=%.1f' % d['value'])"
 done
