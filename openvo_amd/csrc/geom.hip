@@ -251,16 +251,18 @@ extern "C" int vo_ratio_filter(const int32_t* idx, const int32_t* dist, int nq, 
     return VO_OK;
 }
 
-// ratio test + ordered compaction on the device: one wave, ballot prefix
-__global__ void k_ratio_compact(const int32_t* __restrict__ idx, const int32_t* __restrict__ dist, int nq, double ratio,
-                                const float* __restrict__ xy_q, const float* __restrict__ xy_t, int32_t* __restrict__ q_out,
-                                int32_t* __restrict__ t_out, float* __restrict__ xyq_out, float* __restrict__ xyt_out,
-                                int32_t* __restrict__ m_out)
+// ratio test + ordered compaction on the device: one block (any multiple of 64 threads up to 1024), ballot prefix per
+// wave, wave counts carried through LDS
+__global__ void __launch_bounds__(1024) k_ratio_compact(const int32_t* __restrict__ idx, const int32_t* __restrict__ dist, int nq, double ratio,
+                                                        const float* __restrict__ xy_q, const float* __restrict__ xy_t, int32_t* __restrict__ q_out,
+                                                        int32_t* __restrict__ t_out, float* __restrict__ xyq_out, float* __restrict__ xyt_out,
+                                                        int32_t* __restrict__ m_out)
 {
-    const int lane = threadIdx.x;
+    __shared__ int s_cnt[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int base = 0;
-    for (int i0 = 0; i0 < nq; i0 += 64) {
-        int i = i0 + lane;
+    for (int i0 = 0; i0 < nq; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
         bool keep = false;
         int t = -1;
         if (i < nq) {
@@ -268,16 +270,21 @@ __global__ void k_ratio_compact(const int32_t* __restrict__ idx, const int32_t* 
             double a = (double)(float)dist[2 * i], b = (double)(float)dist[2 * i + 1];
             keep = idx[2 * i + 1] >= 0 && a < ratio * b;
         }
-        unsigned long long bal = __ballot(keep);
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int k = 0; k < nw; k++) { const int c = s_cnt[k]; before += k < wv ? c : 0; total += c; }
         if (keep) {
-            int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            const int pos = base + before + __popcll(bal & ((1ull << lane) - 1ull));
             q_out[pos] = i; t_out[pos] = t;
             xyq_out[2 * pos] = xy_q[2 * i]; xyq_out[2 * pos + 1] = xy_q[2 * i + 1];
             xyt_out[2 * pos] = xy_t[2 * t]; xyt_out[2 * pos + 1] = xy_t[2 * t + 1];
         }
-        base += __popcll(bal);
+        base += total;
+        __syncthreads();
     }
-    if (lane == 0) *m_out = base;
+    if (threadIdx.x == 0) *m_out = base;
 }
 
 extern "C" int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int32_t* q_idx, int32_t* t_idx,
@@ -298,7 +305,7 @@ extern "C" int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio
         StageTimer t(ctx, VO_T_MATCH);
         rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->m_idx, ctx->m_dist);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(64), 0, ctx->stream, ctx->m_idx, ctx->m_dist, a.n_kp, ratio, a.kp_xy,
+        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(a.n_kp > 512 ? 1024 : 256), 0, ctx->stream, ctx->m_idx, ctx->m_dist, a.n_kp, ratio, a.kp_xy,
                            b.kp_xy, ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, ctx->m_count);
         VO_CHECK_LAUNCH(ctx);
         // 3-D lookups for every query slot position (n_kp upper bound); only the first M are meaningful

@@ -355,29 +355,7 @@ __device__ __forceinline__ void orb_fast_select(const LevelsDev& L, const int32_
 }
 
 __device__ __forceinline__ int wave_sum_i32(int v);
-
-// Harris response (7x7 block) on the unblurred level, candidate i of this block's level
-__device__ __forceinline__ void orb_harris_one(const LevelDev& d, const uint8_t* pimg,
-                                               const int32_t* candA_pos, float* candA_resp, int i)
-{
-    const int pos = candA_pos[d.cand_off + i];
-    const int w = d.w;
-    const uint8_t* c = pimg + d.off + pos;
-    int a = 0, b = 0, cc = 0;
-    for (int dy = -3; dy <= 3; dy++)
-        for (int dx = -3; dx <= 3; dx++) {
-            const uint8_t* p = c + dy * w + dx;
-            int Ix = (p[1] - p[-1]) * 2 + (p[-w + 1] - p[-w - 1]) + (p[w + 1] - p[w - 1]);
-            int Iy = (p[w] - p[-w]) * 2 + (p[w - 1] - p[-w - 1]) + (p[w + 1] - p[-w + 1]);
-            a += Ix * Ix; b += Iy * Iy; cc += Ix * Iy;
-        }
-    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
-    const float scale4 = scale * scale * scale * scale;
-    const float fa = (float)a, fb = (float)b, fc = (float)cc;
-    const float t1 = fa * fb, t2 = fc * fc, s = fa + fb;
-    const float t4 = (0.04f * s) * s;
-    candA_resp[d.cand_off + i] = ((t1 - t2) - t4) * scale4;
-}
+#define ORB_RANK_LDS 8192      // positions the canonical-order pass of k_orb_select_harris keeps in LDS (32 KB)
 
 __device__ __forceinline__ unsigned f2key(float f)
 {
@@ -437,60 +415,75 @@ __device__ __forceinline__ void orb_harris_select(const LevelsDev& L, const int3
         }
     __syncthreads();
     const int nf = s_nf;
-    // canonical order: ascending position (rank by counting; positions are unique)
+    // canonical order: ascending position (rank by counting; positions are unique).  Every thread reads every position:
+    // from LDS when they fit
+    extern __shared__ int s_tp[];
+    const bool in_lds = nf <= ORB_RANK_LDS;
+    if (in_lds)
+        for (int i = tid; i < nf; i += nt) s_tp[i] = tp[i];
+    __syncthreads();
     for (int i = tid; i < nf; i += nt) {
         const int pi = tp[i];
         int rank = 0;
-        for (int j = 0; j < nf; j++) rank += tp[j] < pi;
+        if (in_lds) for (int j = 0; j < nf; j++) rank += s_tp[j] < pi;
+        else for (int j = 0; j < nf; j++) rank += tp[j] < pi;
         fin_pos[d.cand_off + rank] = pi;
         fin_resp[d.cand_off + rank] = tr[i];
     }
     if (tid == 0) cnt[CNT_FIN + lvl] = nf;
 }
 
-// One block per pyramid level runs the whole selection: retainBest(2*quota) by FAST score -> Harris response
-// of the survivors -> retainBest(quota) by Harris + canonical order.  (Three launches with a mostly empty
-// grid in the middle before; the phases only ever needed block-level synchronisation.)
-// (fin_* alias cand_*: the final lists replace the NMS lists, which are dead by then -- no __restrict__ here)
-__global__ void __launch_bounds__(1024) k_orb_select(const LevelsDev L, const uint8_t* __restrict__ pimg,
-                                                     const int32_t* cand_pos, const float* cand_resp,
-                                                     int32_t* candA_pos, float* candA_resp, int32_t* fin_pos, float* fin_resp,
-                                                     int32_t* tmp_pos, float* tmp_resp, int32_t* cnt)
+// The selection in three launches: one block per pyramid level keeps retainBest(2*quota) by FAST score; the Harris
+// responses of the survivors are one WAVE per candidate across the whole device (lane = one of the 7x7 pixels; at
+// 8000 features there are ~16000 of them and one block per level spent 0.5 ms on this step alone); one block per level
+// keeps retainBest(quota) by Harris and writes the canonical order.
+// (fin_* alias cand_*: the final lists replace the NMS lists, which are dead by then -- no __restrict__ there)
+__global__ void __launch_bounds__(1024) k_orb_select_fast(const LevelsDev L, const int32_t* __restrict__ cand_pos, const float* __restrict__ cand_resp,
+                                                          int32_t* __restrict__ candA_pos, int32_t* __restrict__ cnt)
 {
     __shared__ int s_hist[256];
-    __shared__ int s_thr, s_n, s_remaining, s_nf;
-    __shared__ unsigned s_prefix, s_mask;
+    __shared__ int s_thr, s_n;
     orb_fast_select(L, cand_pos, cand_resp, candA_pos, cnt, s_hist, s_thr, s_n);
-    __syncthreads();
-    const LevelDev d = L.l[blockIdx.x];
-    const int nA = s_n;
-    // Harris response: one WAVE per candidate, lane = one of the 7x7 pixels (integer sums: the order of the additions does
-    // not matter, the float tail is evaluated once by lane 0 exactly as before)
-    {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-        const int dy = lane / 7 - 3, dx = lane % 7 - 3;
-        const int w = d.w;
-        for (int i = wv; i < nA; i += nwv) {
-            const int pos = candA_pos[d.cand_off + i];
-            int a = 0, b = 0, cc = 0;
-            if (lane < 49) {
-                const uint8_t* p = pimg + d.off + pos + dy * w + dx;
-                const int Ix = (p[1] - p[-1]) * 2 + (p[-w + 1] - p[-w - 1]) + (p[w + 1] - p[w - 1]);
-                const int Iy = (p[w] - p[-w]) * 2 + (p[w - 1] - p[-w - 1]) + (p[w + 1] - p[-w + 1]);
-                a = Ix * Ix; b = Iy * Iy; cc = Ix * Iy;
-            }
-            a = wave_sum_i32(a); b = wave_sum_i32(b); cc = wave_sum_i32(cc);
-            if (lane == 0) {
-                const float scale = 1.f / ((1 << 2) * 7 * 255.f);
-                const float scale4 = scale * scale * scale * scale;
-                const float fa = (float)a, fb = (float)b, fc = (float)cc;
-                const float t1 = fa * fb, t2 = fc * fc, sm = fa + fb;
-                const float t4 = (0.04f * sm) * sm;
-                candA_resp[d.cand_off + i] = ((t1 - t2) - t4) * scale4;
-            }
+}
+
+__global__ void __launch_bounds__(256) k_orb_harris(const LevelsDev L, const uint8_t* __restrict__ pimg, const int32_t* __restrict__ candA_pos,
+                                                    float* __restrict__ candA_resp, const int32_t* __restrict__ cnt)
+{
+    const int lvl = blockIdx.y;
+    const LevelDev d = L.l[lvl];
+    const int nA = cnt[CNT_A + lvl];
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwv = gridDim.x * (blockDim.x >> 6);
+    const int dy = lane / 7 - 3, dx = lane % 7 - 3;
+    const int w = d.w;
+    // integer sums: the order of the additions does not matter; the float tail is evaluated once by lane 0
+    for (int i = wv; i < nA; i += nwv) {
+        const int pos = candA_pos[d.cand_off + i];
+        int a = 0, b = 0, cc = 0;
+        if (lane < 49) {
+            const uint8_t* p = pimg + d.off + pos + dy * w + dx;
+            const int Ix = (p[1] - p[-1]) * 2 + (p[-w + 1] - p[-w - 1]) + (p[w + 1] - p[w - 1]);
+            const int Iy = (p[w] - p[-w]) * 2 + (p[w - 1] - p[-w - 1]) + (p[w + 1] - p[-w + 1]);
+            a = Ix * Ix; b = Iy * Iy; cc = Ix * Iy;
+        }
+        a = wave_sum_i32(a); b = wave_sum_i32(b); cc = wave_sum_i32(cc);
+        if (lane == 0) {
+            const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+            const float scale4 = scale * scale * scale * scale;
+            const float fa = (float)a, fb = (float)b, fc = (float)cc;
+            const float t1 = fa * fb, t2 = fc * fc, sm = fa + fb;
+            const float t4 = (0.04f * sm) * sm;
+            candA_resp[d.cand_off + i] = ((t1 - t2) - t4) * scale4;
         }
     }
-    __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) k_orb_select_harris(const LevelsDev L, const int32_t* candA_pos, const float* candA_resp,
+                                                            int32_t* fin_pos, float* fin_resp, int32_t* tmp_pos, float* tmp_resp, int32_t* cnt)
+{
+    __shared__ int s_hist[256];
+    __shared__ int s_remaining, s_nf;
+    __shared__ unsigned s_prefix, s_mask;
     orb_harris_select(L, candA_pos, candA_resp, fin_pos, fin_resp, tmp_pos, tmp_resp, cnt, s_hist, s_prefix, s_mask, s_remaining, s_nf);
 }
 
@@ -675,9 +668,12 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
     hipLaunchKernelGGL(k_orb_fast_nms, dim3(div_up(w - 2 * EDGE, 64), div_up(h - 2 * EDGE, 16), NL), dim3(256), 0, ctx->stream, dL,
                        ctx->orb.pyr_img, ctx->orb.pyr_mask, with_mask, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.counters);
     // after the select, cand_* hold the per-level final lists; candB_* are scratch
-    hipLaunchKernelGGL(k_orb_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.cand_pos, ctx->orb.cand_resp,
-                       ctx->orb.candA_pos, ctx->orb.candA_resp, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.candB_pos,
-                       ctx->orb.candB_resp, ctx->orb.counters);
+    hipLaunchKernelGGL(k_orb_select_fast, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.candA_pos,
+                       ctx->orb.counters);
+    hipLaunchKernelGGL(k_orb_harris, dim3(nfeatures > 2000 ? 256 : 32, NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.candA_pos,
+                       ctx->orb.candA_resp, ctx->orb.counters);
+    hipLaunchKernelGGL(k_orb_select_harris, dim3(NL), dim3(1024), (size_t)ORB_RANK_LDS * 4, ctx->stream, dL, ctx->orb.candA_pos, ctx->orb.candA_resp,
+                       ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.candB_pos, ctx->orb.candB_resp, ctx->orb.counters);
     hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.cand_pos,
                        ctx->orb.cand_resp, ctx->orb.counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, fs->kp_angle,
                        fs->desc);

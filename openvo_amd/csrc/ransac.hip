@@ -346,7 +346,7 @@ extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, c
     {
         StageTimer t(ctx, VO_T_MATCH);
         if ((rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->m_idx, ctx->m_dist))) return rc;
-        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(64), 0, ctx->stream, ctx->m_idx, ctx->m_dist, nq, ratio, a.kp_xy, b.kp_xy,
+        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(nq > 512 ? 1024 : 256), 0, ctx->stream, ctx->m_idx, ctx->m_dist, nq, ratio, a.kp_xy, b.kp_xy,
                            ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, ctx->m_count);
     }
     {

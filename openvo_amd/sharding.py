@@ -201,7 +201,18 @@ class Group:
             return False
         ident = (ctypes.c_uint8 * 128).from_buffer_copy(blob[1:129])
         h = ctypes.c_void_p()
-        rc = L.vo_mgpu_create(int(device), self.rank, self.world, ident, ctypes.byref(h))
+        # communicator creation is a collective: if a peer never arrives it blocks inside RCCL, so it runs on a helper
+        # thread with a deadline (VO_RCCL_TIMEOUT seconds, default 120) and a rank that gives up votes "no" below
+        import threading
+        res = {}
+
+        def _create():
+            res["rc"] = L.vo_mgpu_create(int(device), self.rank, self.world, ident, ctypes.byref(h))
+
+        th = threading.Thread(target=_create, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("VO_RCCL_TIMEOUT", "120")))
+        rc = res.get("rc", -1)
         oks = self.all_gather_bytes(bytes([1 if rc == 0 else 0]))
         if not all(b == b"\x01" for b in oks):
             if rc == 0:
@@ -279,7 +290,7 @@ def init_from_env(want_rccl=True):
     g = Group(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"))
     ndev = device_count()
     device = local if ndev >= world else local % max(ndev, 1)
-    if want_rccl and world > 1 and ndev >= world:
+    if want_rccl and world > 1 and ndev >= world and os.environ.get("VO_NO_RCCL", "0") != "1":
         g.attach_rccl(device)
     return g, device
 

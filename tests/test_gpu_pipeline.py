@@ -419,3 +419,18 @@ def test_failed_prefetch_mid_stream_leaves_the_context_usable(monkeypatch):
     for (a, Ta), (b, Tb) in zip(got, want):
         assert a == b and np.array_equal(Ta, Tb)
     assert np.array_equal(cam.stereoSGBM.compute(*frames[3]), cam2.stereoSGBM.compute(*frames[3]))
+
+
+def test_copy_ceiling_probe_is_sane_and_leaves_the_context_usable(oracle):
+    """vo_measure_copy (the bench's streaming-copy ceiling) returns a plausible rate and, although it scribbles over the
+    cost volume, the next SGBM run is unaffected (every run rebuilds the volumes)."""
+    c = Corridor("C1")
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=500)
+    L, R = c.pair(1)
+    before = cam.stereoSGBM.compute(L, R)
+    for nt in (False, True):
+        rate = cam._ctx.measure_copy(0, 5, nt)
+        assert 100.0 < rate < 16000.0, rate                      # GB/s, read + written; the HBM peak is 8000
+    assert np.array_equal(cam.stereoSGBM.compute(L, R), before)
+    with pytest.raises(Exception):
+        cam._ctx.measure_copy(0, 0, False)                       # reps must be positive
