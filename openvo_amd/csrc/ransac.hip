@@ -239,6 +239,16 @@ __global__ void k_ransac_mask(const float* __restrict__ p1, const float* __restr
     mask[i] = sampson_inlier(Fl, a.x, a.y, b.x, b.y, thr2) ? 1 : 0;
 }
 
+// the five-point kernel keeps its matrices in 100 KB of LDS per wave: above the 64 KB a launch may ask for by default
+static int hyp5_prepare(vo_ctx* ctx)
+{
+    static bool done = false;
+    if (done) return VO_OK;
+    VO_HIP(ctx, hipFuncSetAttribute((const void*)k_ransac_hyp5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FP_LDS_DOUBLES * sizeof(double))));
+    done = true;
+    return VO_OK;
+}
+
 static int ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K4v, int iters, float thr,
                             uint32_t seed, double* E9_out, uint8_t* mask_out, int32_t* counts_out, int32_t* best2_out, int solver)
 {
@@ -269,8 +279,10 @@ static int ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, i
     if (rc) return rc;
     const K4 K{ K4v[0], K4v[1], K4v[2], K4v[3] };
     const float thr2 = thr * thr;
-    if (solver == 5)
-        hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, d_p1, d_p2, n, K, iters, seed, d_E, d_F, nullptr);
+    if (solver == 5) {
+        if (int rc5 = hyp5_prepare(ctx)) return rc5;
+        hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), FP_LDS_DOUBLES * sizeof(double), ctx->stream, d_p1, d_p2, n, K, iters, seed, d_E, d_F, nullptr);
+    }
     else
         hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, d_p1, d_p2, n, K, iters, seed, d_E, d_F, nullptr);
     hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, d_p1, d_p2, n, d_F, iters, thr2, d_counts, nullptr, min_n);
@@ -353,8 +365,10 @@ extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, c
         StageTimer t(ctx, VO_T_POSE);
         const K4 K{ K4v[0], K4v[1], K4v[2], K4v[3] };
         const float thr2 = thr * thr;
-        if (solver == 5)
-            hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, K, iters, seed, d_E, d_F, ctx->m_count);
+        if (solver == 5) {
+            if (int rc5 = hyp5_prepare(ctx)) return rc5;
+            hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), FP_LDS_DOUBLES * sizeof(double), ctx->stream, ctx->xy_a, ctx->xy_b, nq, K, iters, seed, d_E, d_F, ctx->m_count);
+        }
         else
             hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, K, iters, seed, d_E, d_F, ctx->m_count);
         hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, iters, thr2, d_counts, ctx->m_count, min_n);
