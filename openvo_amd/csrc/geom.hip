@@ -1210,7 +1210,7 @@ __global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* _
                                                      float* __restrict__ qb, int lds_m_cap, size_t lds_bits_cap,
                                                      const int* __restrict__ flags_dev, double outlier_thr, int min_matches,
                                                      double* __restrict__ errs, float* __restrict__ ra, float* __restrict__ rb,
-                                                     PoseOut* __restrict__ out, const uint8_t* __restrict__ lanebytes)
+                                                     PoseOut* __restrict__ out, const uint8_t* __restrict__ lanebytes, int* __restrict__ g_sets)
 {
     extern __shared__ __attribute__((aligned(16))) int s_mem[];
     STAMP(0);
@@ -1224,8 +1224,9 @@ __global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* _
         for (int idx = threadIdx.x; idx < m * 4; idx += blockDim.x) dst[idx] = src[idx];
     }
     __syncthreads();
+    // the four per-match int arrays of the greedy loop: LDS, or (more matches than 56 KB of LDS hold) the global workspace
     if (threadIdx.x < 64)
-        pose_clique_wave(s_mem, bits, words_cap, ncons, m_dev, use_filter, pa, pb, qa, qb, &out->n1, lds_m_cap, lds_bits_cap, fast);
+        pose_clique_wave(g_sets ? g_sets : s_mem, bits, words_cap, ncons, m_dev, use_filter, pa, pb, qa, qb, &out->n1, lds_m_cap, lds_bits_cap, fast);
     if (threadIdx.x == 0) out->flags |= *flags_dev;
     STAMP(1);
     __syncthreads();
@@ -1237,7 +1238,7 @@ __global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* _
 size_t pose_ws_bytes(int nq)
 {
     const int words = (nq + 63) / 64;
-    return (size_t)nq * words * 8 + (size_t)nq * 4 + (size_t)nq * 12 * 4 + (size_t)nq * 8 + (size_t)nq * 64 + 4096;
+    return (size_t)nq * words * 8 + (size_t)nq * 4 + (size_t)nq * 12 * 4 + (size_t)nq * 8 + (size_t)nq * 64 + ((size_t)nq + 2) * 16 + 4096;
 }
 
 // PoseOut record is copied to host_out (pinned) at the end.  No host synchronisation.
@@ -1266,6 +1267,7 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
     float* d_ra = (float*)wsp; wsp += (size_t)nq * 12;
     float* d_rb = (float*)wsp; wsp += (size_t)nq * 12;
     uint8_t* d_lanebytes = (uint8_t*)(((uintptr_t)wsp + 15) & ~(uintptr_t)15);
+    int* d_sets = (int*)(d_lanebytes + (size_t)nq * 64);          // 4 x m_cap ints (only used beyond 3584 keypoints)
     int* d_m = ctx->m_count;  // k_pose_prep writes the match count M here
     int rc;
     {
@@ -1291,9 +1293,10 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
         size_t bits_cap = (size_t)nq * words * 8;
         if (nq <= 512 && bits_cap < (size_t)nq * 64) bits_cap = (size_t)nq * 64;   // one byte per (row, lane): the register-resident greedy loop
         if ((size_t)m_cap * 16 + bits_cap > 56 * 1024) bits_cap = 0;
-        hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(1024), (size_t)m_cap * 16 + bits_cap, ctx->stream, d_bits, words, d_ncons, d_m,
+        const bool sets_global = (size_t)m_cap * 16 > 56 * 1024;      // > 3584 keypoints: the sets move to the workspace, LDS stays empty
+        hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(1024), sets_global ? 0 : (size_t)m_cap * 16 + bits_cap, ctx->stream, d_bits, words, d_ncons, d_m,
                            use_filter, ctx->pts_a, ctx->pts_b, d_qa, d_qb, m_cap, bits_cap, d_flags, outlier_thr, min_matches, d_errs,
-                           d_ra, d_rb, d_out, d_lanebytes);
+                           d_ra, d_rb, d_out, d_lanebytes, sets_global ? d_sets : nullptr);
         VO_CHECK_LAUNCH(ctx);
         VO_HIP(ctx, hipMemcpyAsync(host_out, d_out, sizeof(PoseOut), hipMemcpyDeviceToHost, ctx->stream));
     }

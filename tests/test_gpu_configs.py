@@ -200,3 +200,21 @@ def test_c5_mono_pair_device_chain_and_odometer(oracle, c5):
             assert np.abs(Tk[:3, :3] - gt[:3, :3]).max() < 0.02
             assert odo.last["best_count"] > 0.5 * odo.last["matches"]
         prev_c = odo.c_T_w.copy()
+
+
+def test_stereo_pose_step_beyond_the_lds_resident_match_count():
+    """More keypoints than the pose step's LDS-resident sets hold (> 3584: the four per-match arrays of the greedy
+    clique move to the global workspace, the bit rows are read from HBM): two C2 frames with nfeatures = 6000 and the
+    rigidity filter on, against the oracle odometer."""
+    from oracle.odometer import RefStereoCamera, RefStereoOdometer
+    c = Corridor("C2")
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=6000)
+    rcam = _CachedRefCamera(RefStereoCamera(cam.Q, cam.valid_region_left, c.sgbm_params()))
+    kw = dict(nfeatures=6000, rigidity_threshold=0.1, outlier_threshold=0.02, preprocessed_frames=True)
+    odo, rodo = StereoOdometer(cam, **kw), RefStereoOdometer(rcam, **kw)
+    for k, (L, R) in enumerate(c.pairs(30, 2)):
+        a, b = odo.update(L, R), rodo.update(L, R)
+        assert a == b and odo.skip_cause == rodo.skip_cause, k
+        _check_frame(odo, rodo, rcam, cam, k)
+        assert np.allclose(odo.c_T_w, rodo.c_T_w, rtol=0, atol=1e-9), k
+    assert len(odo.current_kps.xy) > 3584, len(odo.current_kps.xy)       # the case this test is about
