@@ -175,7 +175,8 @@ def main():
                 traffic = None
         P = 8 if args.workload == "C4" else 5
         survey_bytes = 2.0 * cells * (1 + P)                            # A_sgbm = 2 B * V * (1 + P)
-        roof = {"bound": "hbm", "kernel": "k_sgbm_paths (%d aggregation directions in one launch; the last one runs fused with the WTA)" % npaths,
+        roof = {"bound": "hbm", "kernel": "k_sgbm_paths (+ k_sgbm_we for pairs on the fused W+E schedule): the %d stored aggregation directions; "
+                                          "the top-down vertical one runs fused with the WTA" % npaths,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "bytes_per_launch": alg_bytes, "launch_us": round(per_launch_s * 1e6, 2), "launches": n_launch,

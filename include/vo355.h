@@ -73,6 +73,11 @@ int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
  * asynchronously; later calls that use the slot wait for it on the device.  Lets the next pair's
  * disparity overlap the current pair's ORB / matching / pose kernels. */
 int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
+/* scheduling hint for the look-ahead: how many pairs the caller will still submit after the next vo_prefetch_* call
+ * (negative = unknown / unbounded).  The library picks, per pair, between two bit-identical aggregation schedules --
+ * the low-latency one for pairs near the head or the end of a stream, the low-traffic one (W and E stored as one
+ * volume) for pairs that sit behind a queue -- and uses this to recognise the end. */
+int vo_set_stream_hint(vo_ctx* ctx, int pairs_remaining);
 /* the same from host images -- the caller's decode/ingest step in front of update():
  * copied to pinned staging, uploaded asynchronously on the engine's stream, then as above.  The host
  * buffers are free again when the call returns. */

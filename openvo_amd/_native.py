@@ -27,7 +27,7 @@ SYMBOLS = [
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints", "vo_download_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_essential5", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
-    "vo_sgbm_last_geometry", "vo_measure_copy", "vo_sgbm_raster_status",
+    "vo_sgbm_last_geometry", "vo_set_stream_hint", "vo_measure_copy", "vo_sgbm_raster_status",
     "vo_upload_mono", "vo_mono_pair",
     "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_last_error",
     "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
@@ -114,6 +114,7 @@ def lib():
         L.vo_sgbm_last_geometry.argtypes = [vp, vp, vp]
         L.vo_sgbm_raster_status.argtypes = [vp, vp]
         L.vo_measure_copy.argtypes = [vp, ctypes.c_int64, ci, ci, vp]
+        L.vo_set_stream_hint.argtypes = [vp, ci]
         L.vo_upload_mono.argtypes = [vp, ci, vp, ci, ci, ci]
         L.vo_mono_pair.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, ci, vp, vp, vp, vp, vp, ci]
         L.vo_device_count.argtypes = [vp]
@@ -229,6 +230,9 @@ class Context:
     def load_staged_pair(self, slot, index, preprocessed):
         self._ck(self._lib.vo_load_staged_pair(self._h, slot, int(index), int(bool(preprocessed))))
         return self.staged_shape
+
+    def set_stream_hint(self, pairs_remaining):
+        self._ck(self._lib.vo_set_stream_hint(self._h, int(pairs_remaining)))
 
     def prefetch_staged_pair(self, slot, index, preprocessed):
         self._ck(self._lib.vo_prefetch_staged_pair(self._h, slot, int(index), int(bool(preprocessed))))

@@ -525,6 +525,114 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
+// the two horizontal directions as ONE stored volume (MODE_SGBM, W1 a multiple of 8)
+// ---------------------------------------------------------------------------------------
+// W and E run along the same image row in opposite directions, so their sum L_W + L_E could be written as one volume
+// if both were known at a pixel at the same time.  The E sweep cannot be held on chip (a row of L is 295 KB at C2), but
+// it can be RECOMPUTED in pieces: pass 1 runs E right-to-left over the row and keeps only every 8th column's L (a
+// checkpoint, 1/8 of a volume); pass 2 walks left-to-right in segments of 8 columns, re-runs E inside the segment from
+// the checkpoint at its right edge (8 columns of L_E in registers), then advances W through the same 8 columns and
+// stores sat(L_W + L_E).  All operands are non-negative, so the saturating sum is order-independent and the fused
+// vertical sweep adds this one volume where it used to add two.  Traffic of the two horizontal directions: C read
+// twice, 1/8 volume written and read, one volume written = 3.25 passes instead of 4, and one volume less for the final
+// sweep to read -- 12.25 passes per pair instead of 14; the price is a third path step per pixel and rows that are
+// three sweeps long.  16 lanes per row, 4 rows per wave, as k_sgbm_paths.
+template <int NP, bool PAD>
+__global__ void __launch_bounds__(256) k_sgbm_we(const int16_t* __restrict__ C, int16_t* __restrict__ Swe, int16_t* __restrict__ ckpt,
+                                                SgbmGeom g, int16_t* __restrict__ dump)
+{
+    const int lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int y = wave * 4 + row;
+    if (wave * 4 >= g.H) return;
+    const bool live = y < g.H;
+    const int yc = live ? y : g.H - 1;
+    const int W1 = g.W1, nseg = W1 >> 3;
+    const int d0 = l16 * 2 * NP;
+    unsigned padreg = 0;
+    if constexpr (PAD) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
+    }
+    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
+    const ptrdiff_t Dp = g.Dp;
+    const int16_t* crow = C + (size_t)yc * W1 * Dp + d0;              // this row of C, this lane's disparities
+    int16_t* const sink = dump + lane * 2 * NP;
+    int16_t* const krow = live ? ckpt + (size_t)yc * nseg * Dp + d0 : sink;   // checkpoints of this row: L_E at x = 8 j
+    const ptrdiff_t kstep = live ? Dp : 0;
+    LV<NP> border;
+#pragma unroll
+    for (int k = 0; k < NP; k++) border.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;
+
+    // ---- pass 1: E, right to left, keeping every 8th column ------------------------------------------------------
+    {
+        LV<NP> Lp = border;
+        uint32_t delta2 = P2_2;
+        LV<NP> cbuf[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) cbuf[k] = lv_load<NP>(crow + (ptrdiff_t)(W1 - 1 - k) * Dp);
+        const int16_t* pld = crow + (ptrdiff_t)(W1 - 9) * Dp;       // (W1 >= 16 is checked by the launcher)
+        for (int s = nseg - 1; s >= 0; s--) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const LV<NP> Cv = cbuf[k];
+                cbuf[k] = lv_load<NP>(pld);
+                pld -= (8 * s - k - 1 > 0) ? Dp : 0;               // next column to fetch is 8 s - k - 1; stop at 0
+                const LV<NP> L = path_step2<NP, PAD>(Cv, Lp, delta2, P1_2, padreg);
+                delta2 = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(L))), P2_2);
+                Lp = L;
+                if (k == 7) lv_store<NP>(krow + (ptrdiff_t)s * kstep, L);   // column 8 s
+            }
+        }
+    }
+    // ---- pass 2: per segment E again (from the checkpoint on its right), then W, store the sum -------------------
+    {
+        LV<NP> LpW = border;
+        uint32_t dW = P2_2;
+        LV<NP> cseg[8], cnext[8], ck, cknext;
+#pragma unroll
+        for (int k = 0; k < 8; k++) cseg[k] = lv_load<NP>(crow + (ptrdiff_t)k * Dp);
+        ck = lv_load<NP>(krow + (ptrdiff_t)(nseg > 1 ? 1 : 0) * kstep);
+        int16_t* pst = live ? Swe + (size_t)yc * W1 * Dp + d0 : sink;
+        const ptrdiff_t sstep = live ? Dp : 0;
+        for (int s = 0; s < nseg; s++) {
+            // prefetch the next segment's costs and checkpoint (clamped at the row's end)
+            const int sn = min(s + 1, nseg - 1);
+#pragma unroll
+            for (int k = 0; k < 8; k++) cnext[k] = lv_load<NP>(crow + (ptrdiff_t)(8 * sn + k) * Dp);
+            cknext = lv_load<NP>(krow + (ptrdiff_t)min(sn + 1, nseg - 1) * kstep);
+            const bool last = s == nseg - 1;                          // the row's last segment starts E from the border
+            LV<NP> LpE;
+#pragma unroll
+            for (int q = 0; q < NP; q++) LpE.r[q] = last ? border.r[q] : ck.r[q];
+            uint32_t dE = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(ck))), P2_2);
+            dE = last ? P2_2 : dE;
+            LV<NP> Le[8];
+#pragma unroll
+            for (int k = 7; k >= 0; k--) {
+                Le[k] = path_step2<NP, PAD>(cseg[k], LpE, dE, P1_2, padreg);
+                dE = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(Le[k]))), P2_2);
+                LpE = Le[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const LV<NP> Lw = path_step2<NP, PAD>(cseg[k], LpW, dW, P1_2, padreg);
+                dW = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(Lw))), P2_2);
+                LpW = Lw;
+                LV<NP> S;
+#pragma unroll
+                for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(Lw.r[q], Le[k].r[q]);
+                lv_store_nt<NP>(pst, S);
+                pst += sstep;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) cseg[k] = cnext[k];
+            ck = cknext;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // winner-take-all: 16 lanes per pixel
 // ---------------------------------------------------------------------------------------
 // winner of one pixel's summed costs: lowest S (first d on ties) and the uniqueness verdict, per 16-lane row.
@@ -1256,6 +1364,44 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
     if (fuse) {
         plan.n_dirs = plan_all.n_dirs - 1;
         for (int k = plan.n_dirs; k < VO_MAX_DIRS; k++) plan.first_wave[k + 1] = plan.first_wave[plan.n_dirs];
+    }
+    // VO_WE_FUSE: W and E as one stored volume (k_sgbm_we), then NW and NE by the line kernel, then the fused sweep over
+    // three volumes.  Layout of S: [0] = L_W + L_E, [1] = NW, [2] = NE, [3] = the E checkpoints (1/8 of a volume).
+    if constexpr (NP % 2 == 0 && NP <= 8) {
+        if (fuse && ctx->we_now && ctx->tune_vwta32 && plan_all.n_dirs == 5 && plan.lpw == 4 && g.W1 % 8 == 0 && g.W1 >= 16) {
+            const bool pad = g.D != g.Dp;
+            {
+                StageTimer t(ctx, VO_T_SGBM_AGG);
+                const int nw = div_up(g.H, 4);
+                if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 3 * vol, g, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 3 * vol, g, ctx->dump);
+                PathPlan pd = plan_all;
+                pd.n_dirs = 2;
+                pd.first_wave[0] = 0;
+                for (int k = 0; k < 2; k++) {
+                    pd.sx[k] = plan_all.sx[2 + k]; pd.sy[k] = plan_all.sy[2 + k]; pd.nlines[k] = plan_all.nlines[2 + k];
+                    pd.first_wave[k + 1] = pd.first_wave[k] + div_up(pd.nlines[k], 4);
+                }
+                for (int k = 2; k < VO_MAX_DIRS; k++) { pd.sx[k] = pd.sy[k] = pd.nlines[k] = 0; pd.first_wave[k + 1] = pd.first_wave[2]; }
+                const int nwaves = pd.first_wave[2];
+                constexpr int PFD = NP <= 4 ? 8 : 4;
+                if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, true>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, vol, g, pd, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, false>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, vol, g, pd, ctx->dump);
+                VO_CHECK_LAUNCH(ctx);
+            }
+            {
+                StageTimer t(ctx, VO_T_SGBM_WTA);
+                constexpr int NP2 = NP / 2;
+                const int nw2 = div_up(g.W1, 2);
+                const size_t sh32 = (size_t)8 * 2 * g.Dp * sizeof(int16_t);
+                if (pad) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 3, true>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
+                else hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 3, false>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
+                hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
+                VO_CHECK_LAUNCH(ctx);
+            }
+            ctx->last_paths = 4;
+            return VO_OK;
+        }
     }
     {
         StageTimer t(ctx, VO_T_SGBM_AGG);

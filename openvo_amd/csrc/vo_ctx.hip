@@ -204,6 +204,10 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     if (const char* e7 = getenv("VO_FUSE_WTA")) ctx->tune_fuse_wta = atoi(e7) ? 1 : 0;
     if (const char* e14 = getenv("VO_VWTA32")) ctx->tune_vwta32 = atoi(e14) ? 1 : 0;
     if (const char* e15 = getenv("VO_PATH_LANES")) ctx->tune_path_lanes = atoi(e15) == 8 ? 8 : 16;
+    if (const char* e16 = getenv("VO_WE_FUSE")) { int v = atoi(e16); ctx->tune_we_fuse = v == 2 ? 2 : (v ? 1 : 0); }
+    if (const char* e17 = getenv("VO_WE_AFTER")) ctx->we_after = atoi(e17);
+    if (const char* e18 = getenv("VO_WE_TAIL")) ctx->we_tail = atoi(e18);
+    ctx->we_now = ctx->tune_we_fuse == 1;
     if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);
     if (const char* e11 = getenv("VO_PRIO")) ctx->tune_prio = atoi(e11);
     if (const char* e12 = getenv("VO_RASTER_AFTER")) ctx->raster_after = atoi(e12);
@@ -598,10 +602,14 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
             // scheme of this pair: with a deep enough queue in front of it the pair is not waited for soon, and the
             // raster scheme (less than half the HBM traffic, long dependency chain) serves throughput; near the head of
             // the queue the line scheme (short chains) serves latency.  Same disparity either way.
-            const int saved = ctx->tune_raster;
+            const int saved = ctx->tune_raster, saved_we = ctx->we_now;
             if (ctx->raster_after >= 0) ctx->tune_raster = ctx->inflight >= ctx->raster_after ? 1 : 0;
+            // likewise the fused horizontal pair (12 % fewer bytes, rows three sweeps long): for pairs behind a queue and
+            // not among the last of the stream
+            if (ctx->tune_we_fuse == 2) ctx->we_now = ctx->inflight >= ctx->we_after && ctx->stream_remaining >= ctx->we_tail;
             rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
             ctx->tune_raster = saved;
+            ctx->we_now = saved_we;
         }
         if (!rc && ctx->la_orb) {
             const int* q = ctx->la_orb_params;
@@ -925,6 +933,13 @@ extern "C" int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemp
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *gb_per_s = ms > 0.f ? 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;   // bytes read + bytes written
+    return VO_OK;
+}
+
+extern "C" int vo_set_stream_hint(vo_ctx* ctx, int pairs_remaining)
+{
+    if (!ctx) return VO_E_ARG;
+    ctx->stream_remaining = pairs_remaining < 0 ? (1 << 30) : pairs_remaining;
     return VO_OK;
 }
 

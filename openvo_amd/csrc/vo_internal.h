@@ -97,7 +97,7 @@ struct vo_ctx {
     bool la_orb = false;
     int la_orb_params[4] = {0, 0, 0, 0};
     int32_t* slot_words = nullptr;   // pinned, one word per slot (keypoint counts of pending runs)
-    int n_engines = 10;              // VO_ENGINES (needs GPU_MAX_HW_QUEUES >= engines + 4: streams sharing a hardware queue serialise)
+    int n_engines = 12;              // VO_ENGINES (needs GPU_MAX_HW_QUEUES >= engines + 4: streams sharing a hardware queue serialise)
     int next_engine = 0;
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;
     std::string err;
@@ -202,6 +202,11 @@ struct vo_ctx {
 
     // tuning knobs (environment: VO_PATH_PF, VO_SWEEP_XT, VO_SWEEP_TY), read once in vo_create
     int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 30;
+    int tune_we_fuse = 2;           // VO_WE_FUSE: W and E stored as one volume (E recomputed per 8-column segment from checkpoints):
+                                    // 0 never, 1 always, 2 per pair -- only with >= we_after pairs in flight and >= we_tail pairs still to come
+    int we_after = 4, we_tail = 8;  // VO_WE_AFTER, VO_WE_TAIL
+    int we_now = 0;                 // the decision for the pair being enqueued
+    int stream_remaining = 1 << 30; // vo_set_stream_hint: pairs the caller will still submit after the next one (unknown = many)
     int tune_path_lanes = 16;       // VO_PATH_LANES: lanes per scan line in k_sgbm_paths (8 = 16 disparities per lane, D <= 128)
     int fault_prefetch = 0;         // VO_FAULT_PREFETCH=n (test hook): the n-th look-ahead submission fails inside its engine scope
     int tune_vwta32 = 1;            // VO_VWTA32: the fused vertical + WTA sweep with 32 lanes per column (twice the waves)

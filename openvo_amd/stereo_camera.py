@@ -131,7 +131,7 @@ class StereoCamera:
         self._slot_gen = [0] * _native.VO_NUM_SLOTS        # bumped whenever a slot receives a new pair
         self._next_slot = 0
         # staged pairs: how many following pairs run their SGBM ahead (default 12, at most VO_NUM_SLOTS - 3; env VO_LOOKAHEAD overrides)
-        self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "12"))
+        self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "14"))
         self._lookahead = []         # [((index, preprocessed), slot, (w, h))] of the pairs in flight
         self._n_staged = 0
 
@@ -308,6 +308,7 @@ class StereoCamera:
                 nxt = self._free_slot()
                 if nxt is None:
                     break
+                self._ctx.set_stream_hint(self._n_staged - 1 - idx)      # pairs still to come after this one
                 shape = self._ctx.prefetch_staged_pair(nxt, idx, preprocessed)
                 self._slot_gen[nxt] += 1
                 self._slot_owner[nxt] = _RESERVED

@@ -25,9 +25,9 @@ def load(path):
     return acc, meta
 
 
-SGBM = ("k_sgbm_planes", "k_sgbm_cost_sweep", "k_sgbm_paths", "k_sgbm_vwta", "k_sgbm_raster", "k_sgbm_fin", "k_lr_median3", "k_ccl_")
+SGBM = ("k_sgbm_planes", "k_sgbm_cost_sweep", "k_sgbm_paths", "k_sgbm_we", "k_sgbm_vwta", "k_sgbm_raster", "k_sgbm_fin", "k_lr_median3", "k_ccl_")
 rows, per_pair = [], {}
-for scheme, name in ((0, "line"), (1, "raster")):
+for scheme, name in ((0, "line"), (1, "raster"), (2, "line_we_fused")):
     f, _ = load(os.path.join(src, "fetch_%d" % scheme, "pmc_counter_collection.csv"))
     w, _ = load(os.path.join(src, "write_%d" % scheme, "pmc_counter_collection.csv"))
     tot_f = tot_w = 0.0
@@ -55,10 +55,10 @@ with open(os.path.join(dst, "%s_occupancy_c2.csv" % tag), "w") as fh:
     fh.write("scheme,kernel,dispatches,grid_threads,workgroup,vgprs,lds_bytes,waves,waves_per_simd_if_all_resident,"
              "valu_busy_frac_of_wave_cycles,active_any_frac,wait_any_frac(parked: s_waitcnt/barrier),wait_inst_any_frac(issue stall),"
              "wave_cycles_per_wave,gui_active_cycles\n")
-    for scheme, name in ((0, "line"), (1, "raster")):
+    for scheme, name in ((0, "line"), (1, "raster"), (2, "line_we_fused")):
         o, meta = load(os.path.join(src, "occ_%d" % scheme, "pmc_counter_collection.csv"))
         for k in sorted(meta):
-            if not k.startswith(("k_sgbm_cost_sweep", "k_sgbm_paths", "k_sgbm_vwta", "k_sgbm_raster", "k_orb_select", "k_pose_solve", "k_orb_describe", "k_orb_fast")):
+            if not k.startswith(("k_sgbm_cost_sweep", "k_sgbm_paths", "k_sgbm_we", "k_sgbm_vwta", "k_sgbm_raster", "k_orb_select", "k_pose_solve", "k_orb_describe", "k_orb_fast")):
                 continue
             g = lambda c: (sum(o[(c, k)]) / len(o[(c, k)])) if o.get((c, k)) else 0.0
             waves, wc = g("SQ_WAVES"), g("SQ_WAVE_CYCLES")
@@ -70,7 +70,8 @@ with open(os.path.join(dst, "%s_occupancy_c2.csv" % tag), "w") as fh:
 
 pk = [r for r in rows if r[0] == "line" and r[1].startswith("k_sgbm_paths")]
 out = {"workload": "C2", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 6 --warmup 2 "
-                                   "--cpu-pairs 0 --no-post`, MI355X; line scheme (default) and raster scheme (VO_RASTER=1)",
+                                   "--cpu-pairs 0 --no-post`, MI355X; line scheme with separate W / E volumes (VO_WE_FUSE=0), raster scheme (VO_RASTER=1), "
+                                   "line scheme with W + E stored as one volume (VO_WE_FUSE=1: what the default per-pair policy picks for pairs behind a queue)",
        "correction": "gfx950: FETCH_SIZE counts wide coalesced (16 B/lane) reads at half -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
        "kernel": pk[0][1] if pk else None,
        "sgbm_path_bytes_per_launch": int((2 * pk[0][3] + pk[0][4]) * 1024) if pk else None,
