@@ -1365,25 +1365,28 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
         plan.n_dirs = plan_all.n_dirs - 1;
         for (int k = plan.n_dirs; k < VO_MAX_DIRS; k++) plan.first_wave[k + 1] = plan.first_wave[plan.n_dirs];
     }
-    // VO_WE_FUSE: W and E as one stored volume (k_sgbm_we), then NW and NE by the line kernel, then the fused sweep over
-    // three volumes.  Layout of S: [0] = L_W + L_E, [1] = NW, [2] = NE, [3] = the E checkpoints (1/8 of a volume).
+    // VO_WE_FUSE: W and E as one stored volume (k_sgbm_we), then the other stored directions by the line kernel (NW, NE;
+    // MODE_HH: also the three bottom-up ones), then the fused sweep over ND + 1 volumes.
+    // Layout of S: [0] = L_W + L_E, [1 .. ND] = the other directions, [ND + 1] = the E checkpoints (1/8 of a volume).
     if constexpr (NP % 2 == 0 && NP <= 8) {
-        if (fuse && ctx->we_now && ctx->tune_vwta32 && plan_all.n_dirs == 5 && plan.lpw == 4 && g.W1 % 8 == 0 && g.W1 >= 16) {
+        if (fuse && ctx->we_now && ctx->tune_vwta32 && plan.lpw == 4 && g.W1 % 8 == 0 && g.W1 >= 16) {
             const bool pad = g.D != g.Dp;
+            const int ND = plan_all.n_dirs - 3;               // stored directions besides W and E: 2 (MODE_SGBM) or 5 (MODE_HH)
             {
                 StageTimer t(ctx, VO_T_SGBM_AGG);
                 const int nw = div_up(g.H, 4);
-                if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 3 * vol, g, ctx->dump);
-                else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 3 * vol, g, ctx->dump);
+                int16_t* ck = ctx->S + (size_t)(ND + 1) * vol;
+                if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ck, g, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ck, g, ctx->dump);
                 PathPlan pd = plan_all;
-                pd.n_dirs = 2;
+                pd.n_dirs = ND;
                 pd.first_wave[0] = 0;
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < ND; k++) {
                     pd.sx[k] = plan_all.sx[2 + k]; pd.sy[k] = plan_all.sy[2 + k]; pd.nlines[k] = plan_all.nlines[2 + k];
                     pd.first_wave[k + 1] = pd.first_wave[k] + div_up(pd.nlines[k], 4);
                 }
-                for (int k = 2; k < VO_MAX_DIRS; k++) { pd.sx[k] = pd.sy[k] = pd.nlines[k] = 0; pd.first_wave[k + 1] = pd.first_wave[2]; }
-                const int nwaves = pd.first_wave[2];
+                for (int k = ND; k < VO_MAX_DIRS; k++) { pd.sx[k] = pd.sy[k] = pd.nlines[k] = 0; pd.first_wave[k + 1] = pd.first_wave[ND]; }
+                const int nwaves = pd.first_wave[ND];
                 constexpr int PFD = NP <= 4 ? 8 : 4;
                 if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, true>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, vol, g, pd, ctx->dump);
                 else hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, false>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, vol, g, pd, ctx->dump);
@@ -1394,12 +1397,14 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
                 constexpr int NP2 = NP / 2;
                 const int nw2 = div_up(g.W1, 2);
                 const size_t sh32 = (size_t)8 * 2 * g.Dp * sizeof(int16_t);
-                if (pad) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 3, true>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
-                else hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 3, false>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
+#define LAUNCH_VWTA32_WE(NV, PAD) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, NV, PAD>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen)
+                if (ND == 2) { if (pad) LAUNCH_VWTA32_WE(3, true); else LAUNCH_VWTA32_WE(3, false); }
+                else { if (pad) LAUNCH_VWTA32_WE(6, true); else LAUNCH_VWTA32_WE(6, false); }
+#undef LAUNCH_VWTA32_WE
                 hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
                 VO_CHECK_LAUNCH(ctx);
             }
-            ctx->last_paths = 4;
+            ctx->last_paths = plan_all.n_dirs - 1;
             return VO_OK;
         }
     }
