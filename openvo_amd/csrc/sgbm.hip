@@ -445,7 +445,8 @@ struct PathPlan {
 // NP = registers per lane (2*NP disparities), LPL = lanes per scan line (LPL * 2 * NP = Dp), 64 / LPL lines per wave.
 // Fewer lanes per line = more disparities per lane: the per-step fixed work (addresses, the min all-reduce, delta) is
 // spread over more cells and the launch has half the waves.
-template <int NP, int PF, int LPL = 16, bool PAD = true>
+// (TAG only makes the launch of the fused W+E schedule -- NW and NE alone, 1 -- a kernel name of its own in profiles)
+template <int NP, int PF, int LPL = 16, bool PAD = true, int TAG = 0>
 __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ C, int16_t* __restrict__ Lbase, size_t vol,
                                                    SgbmGeom g, PathPlan plan, int16_t* __restrict__ dump)
 {
@@ -1388,8 +1389,8 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
                 for (int k = ND; k < VO_MAX_DIRS; k++) { pd.sx[k] = pd.sy[k] = pd.nlines[k] = 0; pd.first_wave[k + 1] = pd.first_wave[ND]; }
                 const int nwaves = pd.first_wave[ND];
                 constexpr int PFD = NP <= 4 ? 8 : 4;
-                if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, true>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, vol, g, pd, ctx->dump);
-                else hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, false>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, vol, g, pd, ctx->dump);
+                if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, true, 1>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, vol, g, pd, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, false, 1>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, vol, g, pd, ctx->dump);
                 VO_CHECK_LAUNCH(ctx);
             }
             {
