@@ -64,6 +64,12 @@ def main():
         return bench_c5(args)
     group, device = sharding.init_from_env()
     rank, world = group.rank, group.world
+    ndev = sharding.device_count()
+    if world > 1 and 0 < ndev < world:
+        # rehearsal with several ranks on one GPU: their hardware queues add up, so each takes its share of the engines
+        share = -(-world // ndev)
+        os.environ.setdefault("VO_ENGINES", str(max(2, 12 // share)))
+        os.environ.setdefault("VO_LOOKAHEAD", str(max(3, 14 // share)))
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
