@@ -167,6 +167,29 @@ def test_raster_scheme_matches_line_scheme(name, mode, monkeypatch):
     assert np.array_equal(out["0"], out["1"])
 
 
+@pytest.mark.parametrize("name,mode,ndisp", [("C1", 0, 64), ("C1", 1, 64), ("C2", 0, 128), ("T0", 0, 48), ("C1", 0, 112), ("C1", 1, 112)])
+def test_fused_horizontal_pair_schedule_is_bit_identical(oracle, name, mode, ndisp, monkeypatch):
+    """VO_WE_FUSE=1: W and E stored as ONE volume (E recomputed per 8-column segment from checkpoints, k_sgbm_we) on
+    every frame -- the default policy only picks it for pairs behind a queue, which short test sequences never have.
+    Same disparity as the schedule with separate volumes and as the oracle: MODE_SGBM and MODE_HH, padded and unpadded
+    disparity ranges (112 -> Dp 128, 48 -> Dp 64), C2 at full size."""
+    c = Corridor(name)
+    L, R = c.pair(4)
+    p = c.sgbm_params(mode)
+    p["numDisparities"] = ndisp
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VO_WE_FUSE", flag)
+        ctx = _native.Context(0, c.w, c.h, max(c.D, ndisp), 64)
+        ctx.set_sgbm(p, mode)
+        out[flag] = ctx.sgbm_compute_host(L, R)
+        ctx.close()
+    assert (c.w - ndisp) % 8 == 0                                   # otherwise the fused schedule is not taken at all
+    assert np.array_equal(out["0"], out["1"])
+    if name != "C2":                                                # (C2 against the oracle: test_c2_* above)
+        assert np.array_equal(out["1"], oracle.sgbm_compute(L, R, p, mode))
+
+
 def test_c5_mono_pair_device_chain_and_odometer(oracle, c5):
     """BASELINE config 5 as ONE device-resident step (vo_mono_pair): slot keypoints -> kNN-2 -> ratio -> 5000-hypothesis
     essential RANSAC with a single host synchronisation; equals the stage-by-stage oracle composition bit for bit
