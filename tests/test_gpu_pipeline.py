@@ -434,3 +434,26 @@ def test_copy_ceiling_probe_is_sane_and_leaves_the_context_usable(oracle):
     assert np.array_equal(cam.stereoSGBM.compute(L, R), before)
     with pytest.raises(Exception):
         cam._ctx.measure_copy(0, 0, False)                       # reps must be positive
+
+
+def test_per_pair_schedule_choice_does_not_change_the_chain(monkeypatch):
+    """The default policy (VO_WE_FUSE=2) lets pairs that sit behind >= 4 others, and are not among the last 8 of the
+    staged stream, take the fused W+E aggregation schedule; the rest keep the separate-volume one.  A 24-pair staged
+    C1 stream must give the same accept flags and bit-identical poses whichever schedule each pair took."""
+    c = Corridor("C1")
+    frames = c.pairs(0, 24)
+    chains = {}
+    for flag in ("0", "2", "1"):
+        monkeypatch.setenv("VO_WE_FUSE", flag)
+        cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=500)
+        odo = StereoOdometer(cam, rigidity_threshold=0.1, outlier_threshold=0.02, preprocessed_frames=True)
+        staged = cam.stage_pairs(frames)
+        chain = []
+        for s in staged:
+            ok = odo.update(s, None)
+            chain.append((ok, odo.skip_cause, odo.c_T_w.copy()))
+        chains[flag] = chain
+        cam._ctx.close()
+    for flag in ("2", "1"):
+        for (a, ca, Ta), (b, cb, Tb) in zip(chains["0"], chains[flag]):
+            assert a == b and ca == cb and np.array_equal(Ta, Tb), flag
