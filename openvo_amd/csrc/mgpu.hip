@@ -152,7 +152,7 @@ static int mg_reserve(vo_mgpu* g, size_t n)
 // all ranks contribute n float64 (n identical on every rank); all receive world*n in rank order
 extern "C" int vo_mgpu_all_gather_f64(vo_mgpu* g, const double* local, int n, double* all)
 {
-    if (!g || !local || !all || n <= 0) return VO_E_ARG;
+    if (!g || !local || !all || n <= 0) return mg_fail(g, VO_E_ARG, "vo_mgpu_all_gather_f64: bad argument");
     MG_HIP(g, hipSetDevice(g->device));
     int rc = mg_reserve(g, (size_t)n);
     if (rc) return rc;
@@ -172,7 +172,7 @@ extern "C" int vo_mgpu_gather_poses(vo_mgpu* g, const double* local_n17, int n_f
 // element-wise max over ranks, in place (the bench's "slowest rank" time); doubles as a barrier
 extern "C" int vo_mgpu_all_reduce_max_f64(vo_mgpu* g, double* v, int n)
 {
-    if (!g || !v || n <= 0) return VO_E_ARG;
+    if (!g || !v || n <= 0) return mg_fail(g, VO_E_ARG, "vo_mgpu_all_reduce_max_f64: bad argument");
     MG_HIP(g, hipSetDevice(g->device));
     int rc = mg_reserve(g, (size_t)n);
     if (rc) return rc;

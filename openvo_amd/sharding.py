@@ -202,7 +202,7 @@ class Group:
         ident = (ctypes.c_uint8 * 128).from_buffer_copy(blob[1:129])
         h = ctypes.c_void_p()
         # communicator creation is a collective: if a peer never arrives it blocks inside RCCL, so it runs on a helper
-        # thread with a deadline (VO_RCCL_TIMEOUT seconds, default 120) and a rank that gives up votes "no" below
+        # thread with a deadline (VO_RCCL_TIMEOUT seconds, default 90) and a rank that gives up votes "no" below
         import threading
         res = {}
 
@@ -211,7 +211,7 @@ class Group:
 
         th = threading.Thread(target=_create, daemon=True)
         th.start()
-        th.join(float(os.environ.get("VO_RCCL_TIMEOUT", "120")))
+        th.join(float(os.environ.get("VO_RCCL_TIMEOUT", "90")))
         rc = res.get("rc", -1)
         oks = self.all_gather_bytes(bytes([1 if rc == 0 else 0]))
         if not all(b == b"\x01" for b in oks):
@@ -224,7 +224,7 @@ class Group:
     def all_gather_f64(self, local):
         """(n,) float64 per rank (same n everywhere) -> (world, n)."""
         local = np.ascontiguousarray(local, np.float64).reshape(-1)
-        if self.world == 1:
+        if self.world == 1 and self._mgpu is None:
             return local[None].copy()
         if self._mgpu is not None:
             out = np.empty((self.world, len(local)), np.float64)
