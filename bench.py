@@ -65,7 +65,8 @@ def main():
     group, device = sharding.init_from_env()
     rank, world = group.rank, group.world
     ndev = sharding.device_count()
-    if world > 1 and 0 < ndev < world:
+    masked = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if world > 1 and 0 < ndev < world and not masked:      # (a launcher that masks devices per rank gives each its own GPU)
         # rehearsal with several ranks on one GPU: their hardware queues add up, so each takes its share of the engines
         share = -(-world // ndev)
         os.environ.setdefault("VO_ENGINES", str(max(2, 12 // share)))
