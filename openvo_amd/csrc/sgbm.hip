@@ -633,6 +633,127 @@ __global__ void __launch_bounds__(256) k_sgbm_we(const int16_t* __restrict__ C, 
     }
 }
 
+// The same pairing for ANY two opposite directions (MODE_HH: W/E, NW/SE, NE/SW): a scan line of direction (sx, sy) is
+// also a scan line of (-sx, -sy) walked from its other end.  Pass 1 runs the backward direction from the line's far end
+// and keeps L at every 8th step (step index i = 8 j, stored AT the pixel it belongs to, in a scratch volume that is
+// otherwise untouched: 1/8 of its lines are written); pass 2 walks forward in 8-step segments, re-runs the backward
+// direction inside the segment from the checkpoint at step 8 (j + 1), advances the forward direction and stores
+// sat(L_fwd + L_bwd) at the pixel.  Lines of a wave differ in length (diagonals): steps past a line's end are computed
+// and discarded by selects, their loads clamped to the line and their stores sent to the dump area, so the body stays
+// straight-line code.  One launch covers all pairs of the plan (wave ranges per pair, as k_sgbm_paths).
+template <int NP, bool PAD>
+__global__ void __launch_bounds__(256) k_sgbm_pair(const int16_t* __restrict__ C, int16_t* __restrict__ Sbase, int16_t* __restrict__ Kbase,
+                                                  size_t vol, SgbmGeom g, PathPlan plan, int16_t* __restrict__ dump)
+{
+    const int lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= plan.first_wave[plan.n_dirs]) return;
+    int dir = 0;
+    while (dir + 1 < plan.n_dirs && wave >= plan.first_wave[dir + 1]) dir++;
+    const int sx = plan.sx[dir], sy = plan.sy[dir];
+    const int line = (wave - plan.first_wave[dir]) * 4 + row;
+    const int W1 = g.W1, H = g.H;
+    int x0 = 0, y0 = 0, n = 0;
+    if (line < plan.nlines[dir]) {
+        if (sy == 0) { y0 = line; x0 = sx > 0 ? 0 : W1 - 1; }
+        else if (sx == 0) { x0 = line; y0 = sy > 0 ? 0 : H - 1; }
+        else {
+            const int ytop = sy > 0 ? 0 : H - 1;
+            if (line < W1) { x0 = line; y0 = ytop; }
+            else { x0 = sx > 0 ? 0 : W1 - 1; y0 = ytop + sy * (line - W1 + 1); }
+        }
+        const int nx = sx > 0 ? W1 - x0 : (sx < 0 ? x0 + 1 : 1 << 30);
+        const int ny = sy > 0 ? H - y0 : (sy < 0 ? y0 + 1 : 1 << 30);
+        n = min(nx, ny);
+    }
+    int nmax = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) nmax = max(nmax, __builtin_amdgcn_readlane(n, r * 16));
+    const int nsegs = (nmax + 7) >> 3;
+
+    const int d0 = l16 * 2 * NP;
+    unsigned padreg = 0;
+    if constexpr (PAD) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
+    }
+    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
+    const ptrdiff_t stride = ((ptrdiff_t)sy * W1 + sx) * g.Dp;      // cells per forward step
+    const size_t start = ((size_t)y0 * W1 + x0) * g.Dp + d0;
+    const int16_t* cp = C + start;
+    int16_t* const sp = Sbase + (size_t)dir * vol + start;
+    int16_t* const kp = Kbase + (size_t)dir * vol + start;
+    int16_t* const sink = dump + lane * 2 * NP;
+    const int last = max(n, 1) - 1;
+    LV<NP> border;
+#pragma unroll
+    for (int k = 0; k < NP; k++) border.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;
+
+    // ---- pass 1: the backward direction from step n - 1 down to 0, checkpoints at steps 8 j ----------------------
+    {
+        LV<NP> Lp = border;
+        uint32_t delta2 = P2_2;
+        for (int j = nsegs - 1; j >= 0; j--) {
+            LV<NP> cseg[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) cseg[k] = lv_load<NP>(cp + (ptrdiff_t)min(8 * j + k, last) * stride);
+#pragma unroll
+            for (int k = 7; k >= 0; k--) {
+                const int i = 8 * j + k;
+                const bool on = i < n;                               // steps past this line's end leave the state alone
+                const LV<NP> L = path_step2<NP, PAD>(cseg[k], Lp, delta2, P1_2, padreg);
+                const uint32_t dn = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(L))), P2_2);
+#pragma unroll
+                for (int q = 0; q < NP; q++) Lp.r[q] = on ? L.r[q] : Lp.r[q];
+                delta2 = on ? dn : delta2;
+                if (k == 0) lv_store<NP>(on ? kp + (ptrdiff_t)i * stride : sink, L);
+            }
+        }
+    }
+    // ---- pass 2: per segment the backward direction again (from the checkpoint at step 8 j + 8), then forward ------
+    {
+        LV<NP> LpF = border;
+        uint32_t dF = P2_2;
+        for (int j = 0; j < nsegs; j++) {
+            LV<NP> cseg[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) cseg[k] = lv_load<NP>(cp + (ptrdiff_t)min(8 * j + k, last) * stride);
+            const bool has_ck = 8 * j + 8 < n;                       // otherwise the backward direction starts inside this segment
+            const LV<NP> ck = lv_load<NP>(has_ck ? kp + (ptrdiff_t)(8 * j + 8) * stride : sink);
+            LV<NP> LpB;
+#pragma unroll
+            for (int q = 0; q < NP; q++) LpB.r[q] = has_ck ? ck.r[q] : border.r[q];
+            uint32_t dB = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(ck))), P2_2);
+            dB = has_ck ? dB : P2_2;
+            LV<NP> Lb[8];
+#pragma unroll
+            for (int k = 7; k >= 0; k--) {
+                const bool on = 8 * j + k < n;
+                const LV<NP> L = path_step2<NP, PAD>(cseg[k], LpB, dB, P1_2, padreg);
+                const uint32_t dn = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(L))), P2_2);
+                Lb[k] = L;
+#pragma unroll
+                for (int q = 0; q < NP; q++) LpB.r[q] = on ? L.r[q] : LpB.r[q];
+                dB = on ? dn : dB;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = 8 * j + k;
+                const bool on = i < n;
+                const LV<NP> Lf = path_step2<NP, PAD>(cseg[k], LpF, dF, P1_2, padreg);
+                const uint32_t dn = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(Lf))), P2_2);
+#pragma unroll
+                for (int q = 0; q < NP; q++) LpF.r[q] = on ? Lf.r[q] : LpF.r[q];
+                dF = on ? dn : dF;
+                LV<NP> S;
+#pragma unroll
+                for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(Lf.r[q], Lb[k].r[q]);
+                lv_store_nt<NP>(on ? sp + (ptrdiff_t)i * stride : sink, S);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // winner-take-all: 16 lanes per pixel
 // ---------------------------------------------------------------------------------------
@@ -1369,6 +1490,52 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
     // VO_WE_FUSE: W and E as one stored volume (k_sgbm_we), then the other stored directions by the line kernel (NW, NE;
     // MODE_HH: also the three bottom-up ones), then the fused sweep over ND + 1 volumes.
     // Layout of S: [0] = L_W + L_E, [1 .. ND] = the other directions, [ND + 1] = the E checkpoints (1/8 of a volume).
+    // MODE_HH with the pair schedule: all three opposite pairs that do not involve the final sweep's own direction
+    // (W/E, NW/SE, NE/SW) as one stored volume each (k_sgbm_pair), the bottom-up vertical direction by the line kernel,
+    // the fused sweep over four volumes.  Layout of S: [0..2] = the pair sums, [3] = S direction, [4..6] = checkpoints.
+    if constexpr (NP % 2 == 0 && NP <= 8) {
+        if (fuse && ctx->we_now && ctx->tune_pair_hh && ctx->tune_vwta32 && plan.lpw == 4 && plan_all.n_dirs == 8) {
+            const bool pad = g.D != g.Dp;
+            {
+                StageTimer t(ctx, VO_T_SGBM_AGG);
+                PathPlan pp = plan_all;
+                const int src[3] = { 0, 2, 3 };                       // (1,0), (1,1), (-1,1): the forward member of each pair
+                pp.n_dirs = 3;
+                pp.first_wave[0] = 0;
+                for (int k = 0; k < 3; k++) {
+                    pp.sx[k] = plan_all.sx[src[k]]; pp.sy[k] = plan_all.sy[src[k]]; pp.nlines[k] = plan_all.nlines[src[k]];
+                    pp.first_wave[k + 1] = pp.first_wave[k] + div_up(pp.nlines[k], 4);
+                }
+                for (int k = 3; k < VO_MAX_DIRS; k++) { pp.sx[k] = pp.sy[k] = pp.nlines[k] = 0; pp.first_wave[k + 1] = pp.first_wave[3]; }
+                const int nwp = pp.first_wave[3];
+                if (pad) hipLaunchKernelGGL((k_sgbm_pair<NP, true>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 4 * vol, vol, g, pp, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_pair<NP, false>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 4 * vol, vol, g, pp, ctx->dump);
+                PathPlan pd = plan_all;
+                pd.n_dirs = 1;
+                pd.sx[0] = plan_all.sx[6]; pd.sy[0] = plan_all.sy[6]; pd.nlines[0] = plan_all.nlines[6];
+                pd.first_wave[0] = 0;
+                for (int k = 0; k < VO_MAX_DIRS; k++) pd.first_wave[k + 1] = div_up(pd.nlines[0], 4);
+                for (int k = 1; k < VO_MAX_DIRS; k++) pd.sx[k] = pd.sy[k] = pd.nlines[k] = 0;
+                const int nwaves = pd.first_wave[1];
+                constexpr int PFD = NP <= 4 ? 8 : 4;
+                if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, true, 1>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + 3 * vol, vol, g, pd, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, false, 1>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + 3 * vol, vol, g, pd, ctx->dump);
+                VO_CHECK_LAUNCH(ctx);
+            }
+            {
+                StageTimer t(ctx, VO_T_SGBM_WTA);
+                constexpr int NP2 = NP / 2;
+                const int nw2 = div_up(g.W1, 2);
+                const size_t sh32 = (size_t)8 * 2 * g.Dp * sizeof(int16_t);
+                if (pad) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 4, true>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
+                else hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 4, false>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
+                hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
+                VO_CHECK_LAUNCH(ctx);
+            }
+            ctx->last_paths = plan_all.n_dirs - 1;
+            return VO_OK;
+        }
+    }
     if constexpr (NP % 2 == 0 && NP <= 8) {
         if (fuse && ctx->we_now && ctx->tune_vwta32 && plan.lpw == 4 && g.W1 % 8 == 0 && g.W1 >= 16) {
             const bool pad = g.D != g.Dp;

@@ -205,6 +205,7 @@ struct vo_ctx {
     int tune_we_fuse = 2;           // VO_WE_FUSE: W and E stored as one volume (E recomputed per 8-column segment from checkpoints):
                                     // 0 never, 1 always, 2 per pair -- only with >= we_after pairs in flight and >= we_tail pairs still to come
     int we_after = 4, we_tail = 8;  // VO_WE_AFTER, VO_WE_TAIL
+    int tune_pair_hh = 1;           // VO_PAIR_HH: MODE_HH pairs all three opposite direction pairs (k_sgbm_pair), not only W/E
     int we_now = 0;                 // the decision for the pair being enqueued
     int stream_remaining = 1 << 30; // vo_set_stream_hint: pairs the caller will still submit after the next one (unknown = many)
     int tune_path_lanes = 16;       // VO_PATH_LANES: lanes per scan line in k_sgbm_paths (8 = 16 disparities per lane, D <= 128)

@@ -190,6 +190,26 @@ def test_fused_horizontal_pair_schedule_is_bit_identical(oracle, name, mode, ndi
         assert np.array_equal(out["1"], oracle.sgbm_compute(L, R, p, mode))
 
 
+def test_pair_schedule_on_ragged_sizes(oracle, monkeypatch):
+    """MODE_HH with the pair schedule forced (k_sgbm_pair: W/E, NW/SE, NE/SW each stored as one volume): image sizes
+    that make every diagonal a different length and leave partial 8-step segments everywhere (width1 = 569, height 471;
+    a 70 x 59 image whose lines are shorter than two segments), padded disparity range -- against the oracle."""
+    c = Corridor("C1")
+    L, R = c.pair(3)
+    for (w, h, ndisp) in ((633, 471, 64), (134, 59, 64), (640, 480, 112)):
+        l, r = np.ascontiguousarray(L[:h, :w]), np.ascontiguousarray(R[:h, :w])
+        p = c.sgbm_params(1)
+        p["numDisparities"] = ndisp
+        ref = oracle.sgbm_compute(l, r, p, 1)
+        for flag in ("0", "1"):
+            monkeypatch.setenv("VO_WE_FUSE", flag)
+            ctx = _native.Context(0, max(w, 64), max(h, 64), ndisp, 64)
+            ctx.set_sgbm(p, 1)
+            got = ctx.sgbm_compute_host(l, r)
+            ctx.close()
+            assert np.array_equal(got, ref), (w, h, ndisp, flag, int((got != ref).sum()))
+
+
 def test_c5_mono_pair_device_chain_and_odometer(oracle, c5):
     """BASELINE config 5 as ONE device-resident step (vo_mono_pair): slot keypoints -> kNN-2 -> ratio -> 5000-hypothesis
     essential RANSAC with a single host synchronisation; equals the stage-by-stage oracle composition bit for bit
