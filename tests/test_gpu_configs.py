@@ -69,9 +69,10 @@ def test_c2_pose_chain_default_and_bench_parameters():
     assert cam._ctx.sgbm_raster_status() == 0
 
 
-def test_c4_full_frame_and_pose_step():
+def test_c4_full_frame_and_pose_step(monkeypatch):
     """BASELINE config 4: 2048x1536, 256 disparities, 8-path MODE_HH -- two full frames against the oracle
-    (disparity, keypoints, descriptors bit-exact) and the pose step between them."""
+    (disparity, keypoints, descriptors bit-exact) and the pose step between them; the first frame also through the
+    pair schedule forced on (three opposite direction pairs stored as one volume each)."""
     from oracle.odometer import RefStereoCamera, RefStereoOdometer
     c = Corridor("C4")
     p = c.sgbm_params(mode=1)
@@ -88,6 +89,13 @@ def test_c4_full_frame_and_pose_step():
             full = cam.stereoSGBM.compute(L, R)                  # the cv2-object seam on the same frame
             assert np.array_equal(full, rcam.last_disp16)
             assert (full[:, :c.D] == -16).all() and (full >= 0).mean() > 0.5
+            monkeypatch.setenv("VO_WE_FUSE", "1")
+            ctx2 = _native.Context(0, c.w, c.h, c.D, 64)
+            ctx2.set_sgbm(p, 1)
+            paired = ctx2.sgbm_compute_host(L, R)
+            ctx2.close()
+            monkeypatch.delenv("VO_WE_FUSE")
+            assert np.array_equal(paired, full)
     assert np.allclose(odo.c_T_w, rodo.c_T_w, rtol=0, atol=1e-9)
     assert np.linalg.norm(odo.c_T_w[:3, 3]) > 0.1                # the camera did move between the two frames
 
