@@ -507,6 +507,8 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
     int16_t* pst = lp;                                              // cell of the current step
     // (the trip count is rounded up to whole groups of PF steps -- the surplus steps only feed the sink --
     // so that the unrolled body is straight-line code and the waits stay partial)
+    // (TAG 2) every line of this wave starts on the image's top row
+    const bool alltop = __builtin_amdgcn_readfirstlane((int)(__ballot(n > 0 && y0 != 0) == 0ull)) != 0;
     for (int i0 = 0; i0 < nmax; i0 += PF) {
 #pragma unroll
         for (int k = 0; k < PF; k++) {
@@ -519,8 +521,20 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
             const uint32_t mn = LPL == 8 ? half_min_u32(lm) : row_min_u32(lm);
             delta2 = pk_add(pk_rep((int)mn), P2_2);
             Lp = L;
-            lv_store_nt<NP>(i < n ? pst : sink, L);
-            pst += stride;
+            if constexpr (TAG == 2) {
+                // band schedule: only the last row of every 8-row band is kept, as rk[dir][y >> 3][x][d] (`vol` carries the
+                // number of bands; every direction of such a launch steps one row down per step).  Lines that start on
+                // the top row (all of N, most of NW / NE) are in row i at step i: for a wave made of such lines the
+                // store is the unrolled body's 8th step and nothing else; the other waves store every step, mostly
+                // into the dump area.
+                const int yy = y0 + i, xx = x0 + i * sx;
+                const bool keep = i < n && (yy & 7) == 7;
+                if (!alltop || (PF == 8 && k == 7))
+                    lv_store<NP>(keep ? Lbase + (((size_t)dir * vol + (size_t)(yy >> 3)) * W1 + xx) * g.Dp + d0 : sink, L);
+            } else {
+                lv_store_nt<NP>(i < n ? pst : sink, L);
+                pst += stride;
+            }
         }
     }
 }
@@ -908,6 +922,93 @@ __global__ void __launch_bounds__(256) k_sgbm_wta(const int16_t* __restrict__ Lb
         else wta_pixel<NP, true, true>(S, g, lane, live, x1, y, myS, disp1, d2key);
     } else {
         wta_pixel<NP, true, false>(S, g, lane, live, x1, y, myS, disp1, d2key);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// band schedule (MODE_SGBM): the three top-down directions are never stored as volumes
+// ---------------------------------------------------------------------------------------
+// N, NW and NE of a row depend on the row above only.  A pre-pass (k_sgbm_paths<..., 2>) walks their lines as usual
+// but keeps only the last row of every 8-row band (3/8 of a volume).  This kernel then finishes the job band by band,
+// in parallel: a workgroup owns TW columns of one band, loads the checkpoint row above it for TW + 16 columns, and
+// recomputes the three directions row by row in LDS -- the columns it needs shrink by one on each side per row, so the
+// 8-column halos are all it ever reads from its neighbours' territory -- adding the stored W+E volume and running the
+// winner-take-all for its own columns.  Nothing here waits for another workgroup, and the final stage has no 720-step
+// serial sweep any more.  16 lanes per pixel, 16 pixels per 256-thread workgroup per step; two state buffers (row above /
+// this row) of 3 directions x (TW + 16) columns x Dp cells in LDS; columns outside the image hold the border state
+// (zeros), whose minimum is 0, so "predecessor outside" needs no special case.
+template <int NP, bool PAD, int TW>
+__global__ void __launch_bounds__(256) k_sgbm_band(const int16_t* __restrict__ C, const int16_t* __restrict__ Swe, const int16_t* __restrict__ rk,
+                                                  int nbands, SgbmGeom g, int16_t* __restrict__ disp1, int* __restrict__ d2key)
+{
+    constexpr int CW = TW + 16;
+    extern __shared__ __attribute__((aligned(16))) int16_t s_band[];   // [2][3][CW][Dp] state, then [16][Dp] WTA scratch
+    const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;   // 16 pixel groups
+    const int Dp = g.Dp, W1 = g.W1, H = g.H;
+    const int band = blockIdx.y, x0 = blockIdx.x * TW, x1 = min(x0 + TW, W1);
+    const int base = x0 - 8;                                             // image column of state column 0
+    const int d0 = l16 * 2 * NP;
+    unsigned padreg = 0;
+    if constexpr (PAD) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
+    }
+    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
+    LV<NP> border;
+#pragma unroll
+    for (int k = 0; k < NP; k++) border.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;
+    const size_t bufsz = (size_t)3 * CW * Dp;
+    int16_t* myS = s_band + 2 * bufsz + (size_t)grp * Dp;
+    // state of the row above the band: the checkpoints of band - 1 (border for the top band and outside the image);
+    // the other buffer starts as border everywhere so that out-of-image columns read as border on every row
+    for (int it = grp; it < 3 * CW; it += 16) {
+        const int dir = it / CW, col = it % CW, x = base + col;
+        LV<NP> v = border;
+        if (band > 0 && x >= 0 && x < W1) v = lv_load<NP>(rk + (((size_t)dir * nbands + (band - 1)) * W1 + x) * Dp + d0);
+        lv_store<NP>(s_band + ((size_t)dir * CW + col) * Dp + d0, v);
+        lv_store<NP>(s_band + bufsz + ((size_t)dir * CW + col) * Dp + d0, border);
+    }
+    __syncthreads();
+    int cur = 1;
+    for (int r = 0; r < 8; r++) {
+        const int y = band * 8 + r;
+        if (y >= H) break;                                               // (uniform)
+        const int lo = max(0, x0 - (7 - r)), hi = min(W1, x1 + (7 - r));
+        const int16_t* prev = s_band + (size_t)(cur ^ 1) * bufsz;
+        int16_t* now = s_band + (size_t)cur * bufsz;
+        const size_t rowoff = (size_t)y * W1;
+        // this group's columns of the row: lo + grp, + 16, + 32 ... (at most (TW + 14 + 15) / 16 of them)
+        constexpr int MAXI = (TW + 14 + 15) / 16;
+        LV<NP> cv[MAXI], sw[MAXI];
+#pragma unroll
+        for (int q = 0; q < MAXI; q++) {
+            const int c = min(lo + grp + 16 * q, W1 - 1);
+            cv[q] = lv_load<NP>(C + (rowoff + c) * Dp + d0);
+            const int cs = (c >= x0 && c < x1) ? c : x0;               // halo columns have no pixel to decide: re-read a cached cell
+            sw[q] = lv_load_nt<NP>(Swe + (rowoff + cs) * Dp + d0);
+        }
+#pragma unroll
+        for (int q = 0; q < MAXI; q++) {
+            const int c = lo + grp + 16 * q;
+            const bool act = c < hi;                                     // lane-group uniform
+            const int cc = act ? c - base : 8;                           // (inactive groups replay a harmless column into scratch-free registers)
+            LV<NP> S = sw[q];
+#pragma unroll
+            for (int dir = 0; dir < 3; dir++) {
+                const int pc = cc + (dir == 1 ? -1 : (dir == 2 ? 1 : 0));   // predecessor column: N same, NW left, NE right
+                const LV<NP> Lp = lv_load<NP>(prev + ((size_t)dir * CW + pc) * Dp + d0);
+                const uint32_t delta2 = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(Lp))), P2_2);
+                const LV<NP> L = path_step2<NP, PAD>(cv[q], Lp, delta2, P1_2, padreg);
+                if (act) lv_store<NP>(now + ((size_t)dir * CW + cc) * Dp + d0, L);
+#pragma unroll
+                for (int k = 0; k < NP; k++) S.r[k] = pk_add_sat(S.r[k], L.r[k]);
+            }
+            const bool live = act && c >= x0 && c < x1;
+            if (__ballot(live) != 0ull)                                  // (wave-uniform: halo-only waves skip the winner search)
+                wta_pixel<NP, PAD, true>(S, g, lane, live, c, y, myS, disp1, d2key);
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 }
 
@@ -1490,6 +1591,49 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
     // VO_WE_FUSE: W and E as one stored volume (k_sgbm_we), then the other stored directions by the line kernel (NW, NE;
     // MODE_HH: also the three bottom-up ones), then the fused sweep over ND + 1 volumes.
     // Layout of S: [0] = L_W + L_E, [1 .. ND] = the other directions, [ND + 1] = the E checkpoints (1/8 of a volume).
+    // Band schedule (MODE_SGBM, VO_BAND): W + E as one volume, row checkpoints of N / NW / NE, then the band kernel.
+    // Layout of S: [0] = L_W + L_E, [1] = row checkpoints (3/8 of a volume), [3] = the E checkpoints of k_sgbm_we.
+    if constexpr (NP <= 4) {
+        if (fuse && ctx->band_now && plan.lpw == 4 && plan_all.n_dirs == 5 && g.W1 % 8 == 0 && g.W1 >= 16 && g.H >= 8) {
+            const bool pad = g.D != g.Dp;
+            const int nb = div_up(g.H, 8);
+            constexpr int TW = 32;
+            const size_t lds = ((size_t)2 * 3 * (TW + 16) + 16) * g.Dp * sizeof(int16_t);
+            static bool attr_done = false;
+            if (!attr_done) {
+                VO_HIP(ctx, hipFuncSetAttribute((const void*)k_sgbm_band<NP, true, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                VO_HIP(ctx, hipFuncSetAttribute((const void*)k_sgbm_band<NP, false, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_done = true;
+            }
+            {
+                StageTimer t(ctx, VO_T_SGBM_AGG);
+                const int nw = div_up(g.H, 4);
+                if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 3 * vol, g, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 3 * vol, g, ctx->dump);
+                PathPlan pd = plan_all;
+                const int src[3] = { 4, 2, 3 };                       // N, NW, NE: the order k_sgbm_band indexes the checkpoints by
+                pd.n_dirs = 3;
+                pd.first_wave[0] = 0;
+                for (int k = 0; k < 3; k++) {
+                    pd.sx[k] = plan_all.sx[src[k]]; pd.sy[k] = plan_all.sy[src[k]]; pd.nlines[k] = plan_all.nlines[src[k]];
+                    pd.first_wave[k + 1] = pd.first_wave[k] + div_up(pd.nlines[k], 4);
+                }
+                for (int k = 3; k < VO_MAX_DIRS; k++) { pd.sx[k] = pd.sy[k] = pd.nlines[k] = 0; pd.first_wave[k + 1] = pd.first_wave[3]; }
+                const int nwaves = pd.first_wave[3];
+                if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, 8, 16, true, 2>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, (size_t)nb, g, pd, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_paths<NP, 8, 16, false, 2>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, (size_t)nb, g, pd, ctx->dump);
+                VO_CHECK_LAUNCH(ctx);
+            }
+            {
+                StageTimer t(ctx, VO_T_SGBM_WTA);
+                if (pad) hipLaunchKernelGGL((k_sgbm_band<NP, true, TW>), dim3(div_up(g.W1, TW), nb), dim3(256), lds, ctx->stream, ctx->C, ctx->S, ctx->S + vol, nb, g, ctx->disp_tmp, ctx->ccl_size);
+                else hipLaunchKernelGGL((k_sgbm_band<NP, false, TW>), dim3(div_up(g.W1, TW), nb), dim3(256), lds, ctx->stream, ctx->C, ctx->S, ctx->S + vol, nb, g, ctx->disp_tmp, ctx->ccl_size);
+                VO_CHECK_LAUNCH(ctx);
+            }
+            ctx->last_paths = 4;
+            return VO_OK;
+        }
+    }
     // MODE_HH with the pair schedule: all three opposite pairs that do not involve the final sweep's own direction
     // (W/E, NW/SE, NE/SW) as one stored volume each (k_sgbm_pair), the bottom-up vertical direction by the line kernel,
     // the fused sweep over four volumes.  Layout of S: [0..2] = the pair sums, [3] = S direction, [4..6] = checkpoints.

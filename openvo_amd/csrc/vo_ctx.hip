@@ -206,6 +206,8 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     if (const char* e15 = getenv("VO_PATH_LANES")) ctx->tune_path_lanes = atoi(e15) == 8 ? 8 : 16;
     if (const char* e16 = getenv("VO_WE_FUSE")) { int v = atoi(e16); ctx->tune_we_fuse = v == 2 ? 2 : (v ? 1 : 0); }
     if (const char* e19 = getenv("VO_PAIR_HH")) ctx->tune_pair_hh = atoi(e19) ? 1 : 0;
+    if (const char* e20 = getenv("VO_BAND")) { int v = atoi(e20); ctx->tune_band = v == 2 ? 2 : (v ? 1 : 0); }
+    ctx->band_now = ctx->tune_band == 1;
     if (const char* e17 = getenv("VO_WE_AFTER")) ctx->we_after = atoi(e17);
     if (const char* e18 = getenv("VO_WE_TAIL")) ctx->we_tail = atoi(e18);
     ctx->we_now = ctx->tune_we_fuse == 1;
@@ -608,9 +610,12 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
             // likewise the fused horizontal pair (12 % fewer bytes, rows three sweeps long): for pairs behind a queue and
             // not among the last of the stream
             if (ctx->tune_we_fuse == 2) ctx->we_now = ctx->inflight >= ctx->we_after && ctx->stream_remaining >= ctx->we_tail;
+            const int saved_band = ctx->band_now;
+            if (ctx->tune_band == 2) ctx->band_now = ctx->inflight >= ctx->we_after && ctx->stream_remaining >= ctx->we_tail;
             rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
             ctx->tune_raster = saved;
             ctx->we_now = saved_we;
+            ctx->band_now = saved_band;
         }
         if (!rc && ctx->la_orb) {
             const int* q = ctx->la_orb_params;

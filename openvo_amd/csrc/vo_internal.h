@@ -205,6 +205,8 @@ struct vo_ctx {
     int tune_we_fuse = 2;           // VO_WE_FUSE: W and E stored as one volume (E recomputed per 8-column segment from checkpoints):
                                     // 0 never, 1 always, 2 per pair -- only with >= we_after pairs in flight and >= we_tail pairs still to come
     int we_after = 4, we_tail = 8;  // VO_WE_AFTER, VO_WE_TAIL
+    int tune_band = 0;              // VO_BAND: 0 never / 1 always / 2 with the per-pair policy of the W+E schedule: N, NW, NE from row checkpoints in 8-row bands (k_sgbm_band)
+    int band_now = 0;
     int tune_pair_hh = 1;           // VO_PAIR_HH: MODE_HH pairs all three opposite direction pairs (k_sgbm_pair), not only W/E
     int we_now = 0;                 // the decision for the pair being enqueued
     int stream_remaining = 1 << 30; // vo_set_stream_hint: pairs the caller will still submit after the next one (unknown = many)

@@ -198,6 +198,30 @@ def test_fused_horizontal_pair_schedule_is_bit_identical(oracle, name, mode, ndi
         assert np.array_equal(out["1"], oracle.sgbm_compute(L, R, p, mode))
 
 
+@pytest.mark.parametrize("name,ndisp,crop", [("C1", 64, None), ("T0", 48, None), ("C1", 112, (640, 477)), ("C2", 128, None)])
+def test_band_schedule_is_bit_identical(oracle, name, ndisp, crop, monkeypatch):
+    """VO_BAND=1 (opt-in experiment): W + E as one volume, N / NW / NE kept only as one checkpoint row per 8-row band, and
+    k_sgbm_band recomputing them per band in LDS tiles with 8-column halos + the winner search -- same disparity as the
+    default schedule and as the oracle (a height that is not a multiple of 8, padded disparity ranges, C2 at full size)."""
+    c = Corridor(name)
+    L, R = c.pair(5)
+    if crop:
+        L, R = np.ascontiguousarray(L[:crop[1], :crop[0]]), np.ascontiguousarray(R[:crop[1], :crop[0]])
+    p = c.sgbm_params(0)
+    p["numDisparities"] = ndisp
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VO_BAND", flag)
+        monkeypatch.setenv("VO_WE_FUSE", "0")
+        ctx = _native.Context(0, c.w, c.h, max(c.D, ndisp), 64)
+        ctx.set_sgbm(p, 0)
+        out[flag] = ctx.sgbm_compute_host(L, R)
+        ctx.close()
+    assert np.array_equal(out["0"], out["1"])
+    if name != "C2":
+        assert np.array_equal(out["1"], oracle.sgbm_compute(L, R, p, 0))
+
+
 def test_pair_schedule_on_ragged_sizes(oracle, monkeypatch):
     """MODE_HH with the pair schedule forced (k_sgbm_pair: W/E, NW/SE, NE/SW each stored as one volume): image sizes
     that make every diagonal a different length and leave partial 8-step segments everywhere (width1 = 569, height 471;
