@@ -69,8 +69,8 @@ def main():
     if world > 1 and 0 < ndev < world and not masked:      # (a launcher that masks devices per rank gives each its own GPU)
         # rehearsal with several ranks on one GPU: their hardware queues add up, so each takes its share of the engines
         share = -(-world // ndev)
-        os.environ.setdefault("VO_ENGINES", str(max(2, 12 // share)))
-        os.environ.setdefault("VO_LOOKAHEAD", str(max(3, 14 // share)))
+        os.environ.setdefault("VO_ENGINES", str(max(2, 8 // share)))        # (2 x 6 engines on one GPU oversubscribe its hardware
+        os.environ.setdefault("VO_LOOKAHEAD", str(max(3, 10 // share)))     #  queues and the rate collapses; 2 x 4 is fine)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
