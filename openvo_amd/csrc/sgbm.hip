@@ -1293,6 +1293,163 @@ __global__ void __launch_bounds__(256) k_sgbm_vwta32(const int16_t* __restrict__
     }
 }
 
+// ---- the same fused sweep with 64 lanes per column (one column per wave): Dp / 128 registers per lane -------------
+// 1152 waves at C2 instead of 576 (more than one per SIMD), each step shorter; only for Dp = 128 or 256.
+__device__ __forceinline__ uint32_t wave64_min_u32(uint32_t v)
+{
+    v = row_min_u32(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // rows (0,1) and (2,3) exchange
+    v = min(r[0], r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // halves exchange
+    return min(q[0], q[1]);
+}
+
+template <int NP>
+__device__ __forceinline__ LV<NP> path_step64(const LV<NP>& Cp, const LV<NP>& Lp, uint32_t delta2, uint32_t P1_2, int lane)
+{
+    LV<NP> out;
+    uint32_t prev_hi = DPP(MAXC2, Lp.r[NP - 1], 0x138);   // wave_shr:1
+    uint32_t next_lo = DPP(MAXC2, Lp.r[0], 0x130);        // wave_shl:1
+    prev_hi = lane == 0 ? MAXC2 : prev_hi;
+    next_lo = lane == 63 ? MAXC2 : next_lo;
+    uint32_t w[NP + 1];
+    w[0] = __builtin_amdgcn_alignbit(Lp.r[0], prev_hi, 16);
+#pragma unroll
+    for (int k = 1; k < NP; k++) w[k] = __builtin_amdgcn_alignbit(Lp.r[k], Lp.r[k - 1], 16);
+    w[NP] = __builtin_amdgcn_alignbit(next_lo, Lp.r[NP - 1], 16);
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const uint32_t nb = pk_add_sat(pk_min(w[k], w[k + 1]), P1_2);
+        const uint32_t m = pk_min(pk_min(Lp.r[k], delta2), nb);
+        out.r[k] = pk_sub(pk_add(Cp.r[k], m), delta2);
+    }
+    return out;
+}
+
+// winner + uniqueness verdict of one pixel held by the whole wave (threshold form; no padded disparities: D = Dp)
+template <int NP>
+__device__ __forceinline__ void wta_core64(const LV<NP>& S, const SgbmGeom& g, int lane, int& minS, int& best, bool& viol)
+{
+    const int d0 = lane * 2 * NP;
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const int d = d0 + 2 * k;
+        const uint32_t k0 = ((S.r[k] & 0xFFFFu) << 8) | (uint32_t)d;
+        const uint32_t k1 = ((S.r[k] >> 16) << 8) | (uint32_t)(d + 1);
+        key = min(key, min(k0, k1));
+    }
+    key = wave64_min_u32(key);
+    minS = (int)(key >> 8);
+    best = (int)(key & 255u);
+    const int ur100 = 100 - g.ur;
+    const int a = minS * 100;
+    int T = (int)((float)a * __builtin_amdgcn_rcpf((float)ur100));
+    T += (T * ur100 < a);
+    T += (T * ur100 < a);
+    T -= ((T - 1) * ur100 >= a);
+    T -= ((T - 1) * ur100 >= a);
+    const uint32_t T2 = pk_rep(min(T, 32768));
+    const int t = min(max(best + 4 - d0, 0), 31);
+    const uint32_t m8 = ((7u << t) >> 5) & ((1u << (2 * NP)) - 1u);       // bits of this lane's disparities within best +- 1
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * k, 1);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * k + 1, 1);
+        const uint32_t excl = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
+        any |= pk_sub_sat_u(T2, S.r[k]) & ~excl;
+    }
+    viol = __ballot(any != 0) != 0ull;
+}
+
+template <int NP, int NV>
+__global__ void __launch_bounds__(256) k_sgbm_vwta64(const int16_t* __restrict__ C, const int16_t* __restrict__ Lbase, size_t vol,
+                                                    SgbmGeom g, int* __restrict__ aux0, int* __restrict__ aux1)
+{
+    extern __shared__ int16_t s_S[];  // [blockDim/64][2][Dp]
+    const int lane = threadIdx.x & 63;
+    const int x1 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (x1 >= g.W1) return;
+    const int d0 = lane * 2 * NP;
+    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
+    const size_t stride = (size_t)g.W1 * g.Dp;
+    const uint32_t start = (uint32_t)(x1 * g.Dp + d0);
+    int16_t* myS = s_S + (size_t)(threadIdx.x >> 6) * 2 * g.Dp;
+    LV<NP> Lp;
+#pragma unroll
+    for (int k = 0; k < NP; k++) Lp.r[k] = 0u;
+    uint32_t delta2 = P2_2;
+    const bool writer = lane == 0;
+    uint32_t aoff = (uint32_t)(x1 + g.minX1);
+    int prec = -1, pbest = 0, par = 0;
+    constexpr int PF = 8;
+    LV<NP> cbuf[PF], lbuf[PF][NV];
+    const int16_t* rowC = C;
+    const int16_t* rowL = Lbase;
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        if (k < g.H) {
+            cbuf[k] = lv_load_nt<NP>(rowC + start);
+#pragma unroll
+            for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
+            rowC += stride;
+            rowL += stride;
+        }
+    }
+    for (int y0 = 0; y0 < g.H; y0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int y = y0 + k;
+            if (y < g.H) {
+                const LV<NP> Cv = cbuf[k];
+                LV<NP> S = lbuf[k][0];
+#pragma unroll
+                for (int v = 1; v < NV; v++)
+#pragma unroll
+                    for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], lbuf[k][v].r[q]);
+                if (y + PF < g.H) {
+                    cbuf[k] = lv_load_nt<NP>(rowC + start);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
+                    rowC += stride;
+                    rowL += stride;
+                }
+                const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
+                const int16_t* prevS = myS + (par ^ 1) * g.Dp;
+                const uint32_t nb = ((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1];
+                const LV<NP> L = path_step64<NP>(Cv, Lp, delta2, P1_2, lane);
+                const uint32_t mn = wave64_min_u32(lane_min16<NP>(L));
+                delta2 = pk_add(pk_rep((int)mn), P2_2);
+                Lp = L;
+#pragma unroll
+                for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], L.r[q]);
+                int minS, best;
+                bool viol;
+                wta_core64<NP>(S, g, lane, minS, best, viol);
+                lv_store<NP>(myS + par * g.Dp + d0, S);
+                if (writer && y > 0) {
+                    aux0[aoff] = prec;
+                    aux1[aoff] = (int)nb;
+                }
+                if (y > 0) aoff += (uint32_t)g.W;
+                prec = viol ? -1 : ((minS << 8) | best);
+                pbest = best;
+                par ^= 1;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
+        const int16_t* prevS = myS + (par ^ 1) * g.Dp;
+        if (writer) {
+            aux0[aoff] = prec;
+            aux1[aoff] = (int)(((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1]);
+        }
+    }
+}
+
 #include "sgbm_raster.inc"
 
 // left-right check of one pixel on the WTA results: disp1 or INVALID
@@ -1710,7 +1867,15 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
                 const int nw2 = div_up(g.W1, 2);
                 const size_t sh32 = (size_t)8 * 2 * g.Dp * sizeof(int16_t);
 #define LAUNCH_VWTA32_WE(NV, PAD) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, NV, PAD>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen)
-                if (ND == 2) { if (pad) LAUNCH_VWTA32_WE(3, true); else LAUNCH_VWTA32_WE(3, false); }
+                bool done64 = false;
+                if constexpr (NP % 4 == 0) {
+                    if (ctx->tune_vwta64 && !pad && ND == 2) {
+                        hipLaunchKernelGGL((k_sgbm_vwta64<NP / 4, 3>), dim3(div_up(g.W1, 4)), dim3(256), (size_t)4 * 2 * g.Dp * sizeof(int16_t), ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
+                        done64 = true;
+                    }
+                }
+                if (done64) {
+                } else if (ND == 2) { if (pad) LAUNCH_VWTA32_WE(3, true); else LAUNCH_VWTA32_WE(3, false); }
                 else { if (pad) LAUNCH_VWTA32_WE(6, true); else LAUNCH_VWTA32_WE(6, false); }
 #undef LAUNCH_VWTA32_WE
                 hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
@@ -1750,7 +1915,15 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
                 const int nw2 = div_up(g.W1, 2);
                 const size_t sh32 = (size_t)8 * 2 * g.Dp * sizeof(int16_t);   // 8 column groups per 256-thread block, two rows of S each
 #define LAUNCH_VWTA32(NV, PAD) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, NV, PAD>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen)
-                if (plan.n_dirs == 4) { if (g.D == g.Dp) LAUNCH_VWTA32(4, false); else LAUNCH_VWTA32(4, true); }
+                bool done64 = false;
+                if constexpr (NP % 4 == 0) {
+                    if (ctx->tune_vwta64 && g.D == g.Dp && plan.n_dirs == 4) {
+                        hipLaunchKernelGGL((k_sgbm_vwta64<NP / 4, 4>), dim3(div_up(g.W1, 4)), dim3(256), (size_t)4 * 2 * g.Dp * sizeof(int16_t), ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
+                        done64 = true;
+                    }
+                }
+                if (done64) {
+                } else if (plan.n_dirs == 4) { if (g.D == g.Dp) LAUNCH_VWTA32(4, false); else LAUNCH_VWTA32(4, true); }
                 else { if (g.D == g.Dp) LAUNCH_VWTA32(7, false); else LAUNCH_VWTA32(7, true); }
 #undef LAUNCH_VWTA32
                 hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);

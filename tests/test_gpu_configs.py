@@ -222,6 +222,23 @@ def test_band_schedule_is_bit_identical(oracle, name, ndisp, crop, monkeypatch):
         assert np.array_equal(out["1"], oracle.sgbm_compute(L, R, p, 0))
 
 
+def test_sweep_with_64_lanes_per_column_is_bit_identical(monkeypatch):
+    """VO_VWTA64=1 (opt-in): the fused vertical + WTA sweep with one column per wave (1152 waves at C2, more than one per
+    SIMD -- what the round-1 review asked to try; slower as measured, kept under test): C2 frame, both schedules."""
+    c = Corridor("C2")
+    L, R = c.pair(7)
+    p = c.sgbm_params(0)
+    out = {}
+    for tag, env in (("ref", {"VO_VWTA64": "0", "VO_WE_FUSE": "0"}), ("v64", {"VO_VWTA64": "1", "VO_WE_FUSE": "0"}), ("v64we", {"VO_VWTA64": "1", "VO_WE_FUSE": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = _native.Context(0, c.w, c.h, c.D, 64)
+        ctx.set_sgbm(p, 0)
+        out[tag] = ctx.sgbm_compute_host(L, R)
+        ctx.close()
+    assert np.array_equal(out["ref"], out["v64"]) and np.array_equal(out["ref"], out["v64we"])
+
+
 def test_pair_schedule_on_ragged_sizes(oracle, monkeypatch):
     """MODE_HH with the pair schedule forced (k_sgbm_pair: W/E, NW/SE, NE/SW each stored as one volume): image sizes
     that make every diagonal a different length and leave partial 8-step segments everywhere (width1 = 569, height 471;
