@@ -1828,7 +1828,12 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
                 constexpr int NP2 = NP / 2;
                 const int nw2 = div_up(g.W1, 2);
                 const size_t sh32 = (size_t)8 * 2 * g.Dp * sizeof(int16_t);
-                if (pad) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 4, true>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
+                if (ctx->tune_vwta_queued == 16 && ctx->tune_we_fuse == 2 && NP <= 4) {   // (8 registers per lane and volume: the 32-lane form wins, measured on config 4)
+                    const int nw16 = div_up(g.W1, 4);
+                    const size_t sh16 = (size_t)2 * 16 * g.Dp * sizeof(int16_t);
+                    if (pad) hipLaunchKernelGGL((k_sgbm_vwta<NP, 4, true>), dim3(div_up(nw16, 4)), dim3(256), sh16, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
+                    else hipLaunchKernelGGL((k_sgbm_vwta<NP, 4, false>), dim3(div_up(nw16, 4)), dim3(256), sh16, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
+                } else if (pad) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 4, true>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
                 else hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 4, false>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
                 hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
                 VO_CHECK_LAUNCH(ctx);
@@ -1874,6 +1879,18 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
                         done64 = true;
                     }
                 }
+                // a pair on this schedule is not waited for soon: the 16-lane form of the sweep (half the waves, a third
+                // fewer instructions per pixel) serves throughput, the 32-lane form latency (VO_VWTA_QUEUED=32 to force it)
+                const int nw16 = div_up(g.W1, 4);
+                const size_t sh16 = (size_t)2 * 16 * g.Dp * sizeof(int16_t);
+#define LAUNCH_VWTA16_WE(NV, PAD) hipLaunchKernelGGL((k_sgbm_vwta<NP, NV, PAD>), dim3(div_up(nw16, 4)), dim3(256), sh16, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen)
+                if (done64) {
+                } else if (ctx->tune_vwta_queued == 16 && ctx->tune_we_fuse == 2 && NP <= 4) {
+                    if (ND == 2) { if (pad) LAUNCH_VWTA16_WE(3, true); else LAUNCH_VWTA16_WE(3, false); }
+                    else { if (pad) LAUNCH_VWTA16_WE(6, true); else LAUNCH_VWTA16_WE(6, false); }
+                    done64 = true;
+                }
+#undef LAUNCH_VWTA16_WE
                 if (done64) {
                 } else if (ND == 2) { if (pad) LAUNCH_VWTA32_WE(3, true); else LAUNCH_VWTA32_WE(3, false); }
                 else { if (pad) LAUNCH_VWTA32_WE(6, true); else LAUNCH_VWTA32_WE(6, false); }

@@ -207,6 +207,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     if (const char* e16 = getenv("VO_WE_FUSE")) { int v = atoi(e16); ctx->tune_we_fuse = v == 2 ? 2 : (v ? 1 : 0); }
     if (const char* e19 = getenv("VO_PAIR_HH")) ctx->tune_pair_hh = atoi(e19) ? 1 : 0;
     if (const char* e22 = getenv("VO_VWTA64")) ctx->tune_vwta64 = atoi(e22) ? 1 : 0;
+    if (const char* e23 = getenv("VO_VWTA_QUEUED")) ctx->tune_vwta_queued = atoi(e23) == 32 ? 32 : 16;
     if (const char* e20 = getenv("VO_BAND")) { int v = atoi(e20); ctx->tune_band = v == 2 ? 2 : (v ? 1 : 0); }
     ctx->band_now = ctx->tune_band == 1;
     if (const char* e17 = getenv("VO_WE_AFTER")) ctx->we_after = atoi(e17);

@@ -207,6 +207,7 @@ struct vo_ctx {
     int we_after = 4, we_tail = 8;  // VO_WE_AFTER, VO_WE_TAIL
     int tune_band = 0;              // VO_BAND: 0 never / 1 always / 2 with the per-pair policy of the W+E schedule: N, NW, NE from row checkpoints in 8-row bands (k_sgbm_band)
     int band_now = 0;
+    int tune_vwta_queued = 16;      // VO_VWTA_QUEUED: lanes per column of the final sweep for pairs the per-pair policy put on the paired schedule (16 / 32)
     int tune_vwta64 = 0;            // VO_VWTA64: the fused vertical + WTA sweep with 64 lanes per column (MODE_SGBM, Dp = 128 / 256)
     int tune_pair_hh = 1;           // VO_PAIR_HH: MODE_HH pairs all three opposite direction pairs (k_sgbm_pair), not only W/E
     int we_now = 0;                 // the decision for the pair being enqueued
