@@ -242,10 +242,10 @@ __global__ void k_ransac_mask(const float* __restrict__ p1, const float* __restr
 // the five-point kernel keeps its matrices in 100 KB of LDS per wave: above the 64 KB a launch may ask for by default
 static int hyp5_prepare(vo_ctx* ctx)
 {
-    static bool done = false;
-    if (done) return VO_OK;
+    static unsigned long long done = 0;         // per device (the attribute belongs to the device's copy of the code object)
+    if ((done >> (ctx->device & 63)) & 1ull) return VO_OK;
     VO_HIP(ctx, hipFuncSetAttribute((const void*)k_ransac_hyp5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FP_LDS_DOUBLES * sizeof(double))));
-    done = true;
+    done |= 1ull << (ctx->device & 63);
     return VO_OK;
 }
 

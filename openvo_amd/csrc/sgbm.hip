@@ -1680,10 +1680,10 @@ static int launch_raster(vo_ctx* ctx, const SgbmGeom& g, const int16_t* Lin, int
                        (size_t)R * 2 * 4 * g.Dp * 2;
     if (!ctx->rs_bnd) VO_HIP(ctx, hipMalloc((void**)&ctx->rs_bnd, (ctx->vol_cells * 3 / 8 + 4096) * 8 + 256));   // first use in this workspace
     auto kern = k_sgbm_raster<NP, PAD, REV, HASIN, WTA>;
-    static bool attr_set = false;     // per instantiation: allow more than 64 KB of dynamic LDS
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;     // per instantiation and device: allow more than 64 KB of dynamic LDS
+    if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
         VO_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set |= 1ull << (ctx->device & 63);
     }
     hipLaunchKernelGGL(kern, dim3(nbands < ctx->tune_raster_wgs ? nbands : ctx->tune_raster_wgs), dim3((R + 2) * 64), lds, ctx->stream, ctx->C, Lin, Sout, ctx->rs_bnd, ctl, g, R, nbands,
                        ctx->ccl_label, ctx->ccl_runlen, ctx->dump);
@@ -1756,11 +1756,11 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, 
             const int nb = div_up(g.H, 8);
             constexpr int TW = 32;
             const size_t lds = ((size_t)2 * 3 * (TW + 16) + 16) * g.Dp * sizeof(int16_t);
-            static bool attr_done = false;
-            if (!attr_done) {
+            static unsigned long long attr_done = 0;   // per device
+            if (!((attr_done >> (ctx->device & 63)) & 1ull)) {
                 VO_HIP(ctx, hipFuncSetAttribute((const void*)k_sgbm_band<NP, true, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 VO_HIP(ctx, hipFuncSetAttribute((const void*)k_sgbm_band<NP, false, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_done = true;
+                attr_done |= 1ull << (ctx->device & 63);
             }
             {
                 StageTimer t(ctx, VO_T_SGBM_AGG);
