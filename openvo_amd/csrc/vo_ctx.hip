@@ -922,6 +922,12 @@ extern "C" int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemp
     bytes &= ~(int64_t)4095;
     if (bytes <= 0 || !ctx->C || !ctx->S) return vo_fail(ctx, VO_E_STATE, "vo_measure_copy: no volumes to copy between");
     VO_HIP(ctx, hipSetDevice(ctx->device));
+    // the volumes belong to the main workspace (engine 0 uses it too): nothing of the pipeline may still be running
+    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) {
+        if (ctx->la_stream[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream[k]));
+        if (ctx->la_stream_hi[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream_hi[k]));
+    }
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipEvent_t e0, e1;
     VO_HIP(ctx, hipEventCreate(&e0));
     VO_HIP(ctx, hipEventCreate(&e1));
