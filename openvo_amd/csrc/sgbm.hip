@@ -600,6 +600,8 @@ __global__ void __launch_bounds__(256) k_sgbm_we(const int16_t* __restrict__ C, 
             }
         }
     }
+    // (the checkpoints are read back by the lanes that wrote them: let the stores land before the first load is issued)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- pass 2: per segment E again (from the checkpoint on its right), then W, store the sum -------------------
     {
         LV<NP> LpW = border;
@@ -724,6 +726,7 @@ __global__ void __launch_bounds__(256) k_sgbm_pair(const int16_t* __restrict__ C
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // checkpoint stores land before their lanes read them back
     // ---- pass 2: per segment the backward direction again (from the checkpoint at step 8 j + 8), then forward ------
     {
         LV<NP> LpF = border;
