@@ -266,7 +266,7 @@ def bench_c5(args):
     solver = int(os.environ.get("VO_C5_SOLVER", "5"))
     odo = MonoOdometer(Kmat, (c.w, c.h), nfeatures=nfeat, ransac_iters=iters, device=device, solver=solver)
     first = group.rank * K_steps
-    n_img = min(W + K_steps, 48)                       # the stream wraps around a 48-frame window (0.1 GB of HBM)
+    n_img = min(W + K_steps, 256)                      # beyond 256 frames the stream wraps around (1 GB of HBM); the wrap's pair is rejected
     frames = [c.pair(first + k)[0] for k in range(n_img)]
     odo.stage_frames(frames)
     ctx = odo._ctx
@@ -289,7 +289,7 @@ def bench_c5(args):
     dt = group.all_reduce_max(dt)
     tm = ctx.timings(reset=True)
     if group.rank == 0:
-        n_kp = ctx.orb_slot_count(odo._slot ^ 1, nfeat, 0)
+        n_kp = ctx.orb_slot_count(odo._ref[0], nfeat, 0)
         pair_dists = float(n_kp) * n_kp * K_steps       # ~ keypoints^2 Hamming distances (256 bit) per pair
         match_s, pose_s = tm["match"][0] / 1e3, tm["pose"][0] / 1e3
         # vector-ALU peak: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 7.86e13 32-bit lane-ops/s; one 256-bit Hamming distance is

@@ -204,6 +204,9 @@ int vo_ransac_essential5(vo_ctx* ctx, const float* pts1, const float* pts2, int 
  * ratio test, winning hypothesis, its inlier count}; E9_out = the winner; mask_out / q_idx / t_idx (each `cap`
  * entries, may be NULL): inlier flag, query and train keypoint index of the first counts3[0] entries. */
 int vo_upload_mono(vo_ctx* ctx, int slot, const uint8_t* img, int w, int h, int channels);
+/* look-ahead for a monocular stream: the left image of staged pair `index` into `slot` and its ORB extraction (mask_mode
+ * 0) on a look-ahead engine's stream; a later vo_orb_detect_and_compute(slot, nfeatures, 0, ...) only waits for it */
+int vo_prefetch_staged_mono(vo_ctx* ctx, int slot, int index, int nfeatures);
 int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4, int iters, float thr, uint32_t seed,
                  int solver, double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx, int cap);
 

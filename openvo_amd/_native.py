@@ -28,7 +28,7 @@ SYMBOLS = [
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_essential5", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
     "vo_sgbm_last_geometry", "vo_set_stream_hint", "vo_measure_copy", "vo_sgbm_raster_status",
-    "vo_upload_mono", "vo_mono_pair",
+    "vo_upload_mono", "vo_prefetch_staged_mono", "vo_mono_pair",
     "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_last_error",
     "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
 ]
@@ -116,6 +116,7 @@ def lib():
         L.vo_measure_copy.argtypes = [vp, ctypes.c_int64, ci, ci, vp]
         L.vo_set_stream_hint.argtypes = [vp, ci]
         L.vo_upload_mono.argtypes = [vp, ci, vp, ci, ci, ci]
+        L.vo_prefetch_staged_mono.argtypes = [vp, ci, ci, ci]
         L.vo_mono_pair.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, ci, vp, vp, vp, vp, vp, ci]
         L.vo_device_count.argtypes = [vp]
         L.vo_mgpu_unique_id.argtypes = [vp]
@@ -327,6 +328,14 @@ class Context:
                                                  _p(b["octave"]), _p(b["desc"]), cap, ctypes.byref(n)))
         return self._trim(b, n.value)
 
+    def download_keypoints_xy(self, slot):
+        """Only the (n, 2) float32 positions of a slot's keypoints (the other fields stay on the device)."""
+        cap = self.kp_cap
+        xy = np.empty((cap, 2), np.float32)
+        n = ctypes.c_int(0)
+        self._ck(self._lib.vo_download_keypoints(self._h, slot, _p(xy), None, None, None, None, None, cap, ctypes.byref(n)))
+        return xy[:n.value]
+
     def orb_host(self, img, mask, nfeatures):
         img = np.asarray(img)
         if img.dtype != np.uint8 or img.ndim != 2:
@@ -442,6 +451,9 @@ class Context:
         h, w = img.shape[:2]
         self._ck(self._lib.vo_upload_mono(self._h, slot, _p(img), w, h, ch))
         return w, h
+
+    def prefetch_staged_mono(self, slot, index, nfeatures):
+        self._ck(self._lib.vo_prefetch_staged_mono(self._h, int(slot), int(index), int(nfeatures)))
 
     def mono_pair(self, slot_a, slot_b, ratio, K4, iters=5000, thr=1.0, seed=4321, want_matches=False, solver=8):
         """kNN-2 + ratio + essential-matrix RANSAC between two slots' keypoints, all on the device, one sync.

@@ -653,6 +653,48 @@ extern "C" int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int pre
                          ctx->staged_h, ctx->staged_ch, preprocessed);
 }
 
+// monocular look-ahead (config 5): the left image of a staged pair into a slot and its ORB extraction (no disparity
+// mask), all on a look-ahead engine's stream; vo_orb_detect_and_compute with the same nfeatures / mask_mode 0 then only
+// waits.  The main stream keeps matching and scoring the previous pair meanwhile.
+extern "C" int vo_prefetch_staged_mono(vo_ctx* ctx, int slot, int index, int nfeatures)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (index < 0 || index >= ctx->staged_n) return vo_fail(ctx, VO_E_ARG, "vo_prefetch_staged_mono: bad index");
+    if (nfeatures < 0 || nfeatures > ctx->max_kp) return vo_fail(ctx, VO_E_CAP, "nfeatures %d exceeds max_kp %d", nfeatures, ctx->max_kp);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    FrameSlot& f = ctx->slots[slot];
+    // a monocular extraction is short: four engines cover any useful look-ahead (an engine's first use allocates its workspaces)
+    const int span = ctx->n_engines < 4 ? ctx->n_engines : 4;
+    const int engine = ctx->mono_engine % span;
+    if ((rc = engine_prepare(ctx, engine))) return rc;
+    ctx->mono_engine = (engine + 1) % span;
+    const size_t per = (size_t)ctx->staged_w * ctx->staged_h * ctx->staged_ch;
+    const int w = ctx->staged_w, h = ctx->staged_h;
+    f.w = w; f.h = h; f.has_kp = false; f.n_kp = 0; f.kp_pending = false; f.has_disp = false;
+    {
+        EngineScope on_engine(ctx, engine);
+        {
+            StageTimer t(ctx, VO_T_UPLOAD);
+            rc = ingest(ctx, 0, ctx->staged + per * 2 * index, w, h, ctx->staged_ch, 1, f.left, ctx->stage_in, hipMemcpyDeviceToDevice);
+        }
+        const int params[4] = { nfeatures, 0, 0, 0 };
+        if (!rc) rc = orb_slot_enqueue(ctx, f, nfeatures, 0, 0, 0);
+        if (!rc) { memcpy(f.kp_params, params, sizeof(f.kp_params)); f.kp_pending = true; }
+        if (!rc && hipEventRecord(f.ready, ctx->stream) != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
+    }
+    if (rc) {
+        f.kp_pending = false; f.has_pair = false;
+        if (f.pending && ctx->inflight > 0) ctx->inflight--;
+        f.pending = false;
+        return rc;
+    }
+    f.has_pair = true;
+    if (!f.pending) ctx->inflight++;
+    f.pending = true;
+    return VO_OK;
+}
+
 // the same from host images (the user's decode/ingest step): the upload of pair i+k overlaps the work
 // on pair i; the host buffers are free again when the call returns
 extern "C" int vo_prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* left, const uint8_t* right, int w, int h, int channels,

@@ -210,6 +210,7 @@ struct vo_ctx {
     int tune_vwta_queued = 16;      // VO_VWTA_QUEUED: lanes per column of the final sweep for pairs the per-pair policy put on the paired schedule (16 / 32)
     int tune_vwta64 = 0;            // VO_VWTA64: the fused vertical + WTA sweep with 64 lanes per column (MODE_SGBM, Dp = 128 / 256)
     int tune_pair_hh = 1;           // VO_PAIR_HH: MODE_HH pairs all three opposite direction pairs (k_sgbm_pair), not only W/E
+    int mono_engine = 0;            // round robin of vo_prefetch_staged_mono
     int we_now = 0;                 // the decision for the pair being enqueued
     int stream_remaining = 1 << 30; // vo_set_stream_hint: pairs the caller will still submit after the next one (unknown = many)
     int tune_path_lanes = 16;       // VO_PATH_LANES: lanes per scan line in k_sgbm_paths (8 = 16 disparities per lane, D <= 128)

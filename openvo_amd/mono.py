@@ -13,6 +13,8 @@ host (a dozen flops per inlier); the translation scale is unobservable, so the c
 Parity: every device stage equals the build's own CPU restatement bit for bit (tests/test_gpu_configs.py);
 there is no openVO oracle for this class.
 """
+import os
+
 import numpy as np
 
 from . import _native
@@ -65,45 +67,72 @@ class MonoOdometer:
         self.nfeatures, self.match_threshold = int(nfeatures), float(match_threshold)
         self.ransac_iters, self.ransac_threshold, self.min_inliers, self.seed = int(ransac_iters), float(ransac_threshold), int(min_inliers), int(seed)
         self.c_T_w = np.eye(4)           # world (= first frame) expressed in the current camera frame, like StereoOdometer
-        self._slot, self._have_prev = 0, False
         self.last = None                 # dict of the last pair step
         self.skip_cause = ""
+        # staged streams run ahead: the ORB extraction of the next frames is enqueued on look-ahead engines
+        # (vo_prefetch_staged_mono) while the main stream matches and scores the current pair
+        self.lookahead = int(os.environ.get("VO_MONO_LOOKAHEAD", "3"))
+        self._free = list(range(8))      # frame slots this odometer uses
+        self._ahead = {}                 # staged index -> slot with its extraction in flight
+        self._ref = None                 # (slot, xy) of the reference frame
+        self._n_staged = 0
 
     def stage_frames(self, frames):
         """Keep a list of images resident in HBM; update(k) with an int then reads frame k from there."""
         self._ctx.stage_pairs([(f, f) for f in frames])
+        self._n_staged = len(frames)
+        for s in self._ahead.values():
+            self._free.append(s)
+        self._ahead = {}
 
     def update(self, img, scale=1.0):
         """One frame (an image, or the index of a staged one); True when a relative pose was accepted (always True
         for the very first frame)."""
-        ctx, cur = self._ctx, self._slot
-        if isinstance(img, (int, np.integer)):
-            ctx.load_staged_pair(cur, int(img), True)
+        ctx = self._ctx
+        staged = isinstance(img, (int, np.integer))
+        if staged and int(img) in self._ahead:
+            cur = self._ahead.pop(int(img))                       # extraction already running on an engine
         else:
-            ctx.upload_mono(cur, np.asarray(img))
+            for s in self._ahead.values():                        # out-of-order request: the predictions are void
+                self._free.append(s)
+            self._ahead = {}
+            cur = self._free.pop()
+            if staged:
+                ctx.load_staged_pair(cur, int(img), True)
+            else:
+                ctx.upload_mono(cur, np.asarray(img))
+        if staged:
+            for j in range(int(img) + 1, min(int(img) + 1 + self.lookahead, self._n_staged)):
+                if j not in self._ahead and len(self._free) > 1:
+                    nxt = self._free.pop()
+                    ctx.prefetch_staged_mono(nxt, j, self.nfeatures)
+                    self._ahead[j] = nxt
         n = ctx.orb_slot_count(cur, self.nfeatures, 0)
         if n < 8:
             self.skip_cause = "keypoints"
+            self._free.append(cur)
             return False
-        if not self._have_prev:
-            self._have_prev, self._slot = True, 1 - cur
+        if self._ref is None:
+            self._ref = (cur, ctx.download_keypoints_xy(cur).astype(np.float64))
             return True
-        prev = 1 - cur
+        prev, xy_prev = self._ref
         r = ctx.mono_pair(prev, cur, self.match_threshold, self.K4, self.ransac_iters, self.ransac_threshold, self.seed, want_matches=True, solver=self.solver)
         self.last = r
         need = 6 if self.solver == 5 else 8
         if r["matches"] < need or r["best_count"] < self.min_inliers:
             self.skip_cause = "matches" if r["matches"] < need else "inliers"
+            self._free.append(cur)
             return False                 # the previous frame stays the reference
         inl = np.nonzero(r["mask"])[0][:512]                      # a few hundred inliers decide the cheirality vote
-        xa = ctx.download_keypoints(prev)["xy"][r["q"][inl]].astype(np.float64)
-        xb = ctx.download_keypoints(cur)["xy"][r["t"][inl]].astype(np.float64)
+        xy_cur = ctx.download_keypoints_xy(cur).astype(np.float64)
+        xa, xb = xy_prev[r["q"][inl]], xy_cur[r["t"][inl]]
         fx, fy, cx, cy = self.K4
         R, t, _ = recover_pose(r["E"], (xa - [cx, cy]) / [fx, fy], (xb - [cx, cy]) / [fx, fy])
         T = np.eye(4)
         T[:3, :3], T[:3, 3] = R, t / max(np.linalg.norm(t), 1e-300) * float(scale)
         self.c_T_w = T @ self.c_T_w
-        self._slot = prev                # the new frame becomes the reference; the old slot is reused
+        self._free.append(prev)          # the new frame becomes the reference; the old slot is reused
+        self._ref = (cur, xy_cur)
         return True
 
     def current_pose(self):

@@ -310,3 +310,28 @@ def test_stereo_pose_step_beyond_the_lds_resident_match_count():
         _check_frame(odo, rodo, rcam, cam, k)
         assert np.allclose(odo.c_T_w, rodo.c_T_w, rtol=0, atol=1e-9), k
     assert len(odo.current_kps.xy) > 3584, len(odo.current_kps.xy)       # the case this test is about
+
+
+def test_mono_lookahead_gives_the_same_chain():
+    """MonoOdometer on a staged stream: the ORB extraction of the next frames runs ahead on look-ahead engines
+    (vo_prefetch_staged_mono) while the current pair is matched and scored; accept flags, inlier counts and poses are
+    identical to the one-frame-at-a-time run, also when a frame is asked for out of order."""
+    from openvo_amd.mono import MonoOdometer
+    c = Corridor("C5")
+    K = np.array([[c.f, 0, c.cx], [0, c.f, c.cy], [0, 0, 1.0]])
+    frames = [c.pair(k)[0] for k in range(7)]
+    order = [0, 1, 2, 3, 5, 4, 6]                                      # one request the look-ahead did not predict
+    chains = {}
+    for depth in (0, 3):
+        odo = MonoOdometer(K, (c.w, c.h), nfeatures=3000, ransac_iters=1500)
+        odo.lookahead = depth
+        odo.stage_frames(frames)
+        chain = []
+        for k in order:
+            ok = odo.update(k)
+            chain.append((ok, odo.skip_cause, None if odo.last is None else (odo.last["matches"], odo.last["best_iter"], odo.last["best_count"]), odo.c_T_w.copy()))
+        chains[depth] = chain
+        odo._ctx.close()
+    for (a, ca, la, Ta), (b, cb, lb, Tb) in zip(chains[0], chains[3]):
+        assert a == b and ca == cb and la == lb and np.array_equal(Ta, Tb)
+    assert sum(x[0] for x in chains[3]) >= 6
