@@ -66,7 +66,9 @@ class MonoOdometer:
         self._ctx = context or _native.Context(device, max(w, 64), max(h, 64), 16, int(nfeatures))
         self.nfeatures, self.match_threshold = int(nfeatures), float(match_threshold)
         self.ransac_iters, self.ransac_threshold, self.min_inliers, self.seed = int(ransac_iters), float(ransac_threshold), int(min_inliers), int(seed)
-        self.c_T_w = np.eye(4)           # world (= first frame) expressed in the current camera frame, like StereoOdometer
+        self._c_T_w = np.eye(4)          # world (= first frame) expressed in the current camera frame, like StereoOdometer
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool, self._pending = ThreadPoolExecutor(1), None    # the last accepted pair's pose recovery runs beside the next pair's GPU work
         self.last = None                 # dict of the last pair step
         self.skip_cause = ""
         # staged streams run ahead: the ORB extraction of the next frames is enqueued on look-ahead engines
@@ -127,13 +129,32 @@ class MonoOdometer:
         xy_cur = ctx.download_keypoints_xy(cur).astype(np.float64)
         xa, xb = xy_prev[r["q"][inl]], xy_cur[r["t"][inl]]
         fx, fy, cx, cy = self.K4
-        R, t, _ = recover_pose(r["E"], (xa - [cx, cy]) / [fx, fy], (xb - [cx, cy]) / [fx, fy])
-        T = np.eye(4)
-        T[:3, :3], T[:3, 3] = R, t / max(np.linalg.norm(t), 1e-300) * float(scale)
-        self.c_T_w = T @ self.c_T_w
+        # E -> (R, t) is host arithmetic on a few hundred inliers: it runs on a worker thread while this thread is inside
+        # the next frame's native calls (which release the GIL); c_T_w / current_pose() collect it
+        self._flush()
+        self._pending = (self._pool.submit(recover_pose, r["E"].copy(), (xa - [cx, cy]) / [fx, fy], (xb - [cx, cy]) / [fx, fy]), float(scale))
         self._free.append(prev)          # the new frame becomes the reference; the old slot is reused
         self._ref = (cur, xy_cur)
         return True
+
+    def _flush(self):
+        if self._pending is not None:
+            fut, scale = self._pending
+            self._pending = None
+            R, t, _ = fut.result()
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = R, t / max(np.linalg.norm(t), 1e-300) * scale
+            self._c_T_w = T @ self._c_T_w
+
+    @property
+    def c_T_w(self):
+        self._flush()
+        return self._c_T_w
+
+    @c_T_w.setter
+    def c_T_w(self, value):
+        self._flush()
+        self._c_T_w = np.asarray(value, np.float64)
 
     def current_pose(self):
         return np.linalg.inv(self.c_T_w)
