@@ -63,6 +63,7 @@ class MonoOdometer:
         K = np.asarray(K, np.float64)
         self.K, self.K4 = K, [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]
         w, h = int(img_size[0]), int(img_size[1])
+        self._own_ctx = context is None
         self._ctx = context or _native.Context(device, max(w, 64), max(h, 64), 16, int(nfeatures))
         self.nfeatures, self.match_threshold = int(nfeatures), float(match_threshold)
         self.ransac_iters, self.ransac_threshold, self.min_inliers, self.seed = int(ransac_iters), float(ransac_threshold), int(min_inliers), int(seed)
@@ -155,6 +156,13 @@ class MonoOdometer:
     def c_T_w(self, value):
         self._flush()
         self._c_T_w = np.asarray(value, np.float64)
+
+    def close(self):
+        """Collect the pending pose, stop the worker thread and release the native context (if this object created it)."""
+        self._flush()
+        self._pool.shutdown(wait=True)
+        if self._own_ctx:
+            self._ctx.close()
 
     def current_pose(self):
         return np.linalg.inv(self.c_T_w)
