@@ -242,6 +242,10 @@ int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemporal, doubl
 /* health of the raster aggregation sweeps (synchronises): *error_out != 0 when a wait between rows / bands
  * ever exceeded its poll limit (the affected disparities are then undefined); sticky until vo_destroy */
 int vo_sgbm_raster_status(vo_ctx* ctx, int* error_out);
+/* development aid: control block `block` (0 | 1) of the latest aggregation sweep in the main workspace -- word 0 = work items
+   taken, word 1 = sticky error, words 8 + 8 s .. = {start, end, failed polls, ticks waiting, misses} of strip s (100 MHz ticks).
+   No reference counterpart (stereosgbm.cpp is one sequential pass). */
+int vo_sgbm_sweep_stats(vo_ctx* ctx, int block, int32_t* out, int n_words);
 
 /* multi-GPU ----------------------------------------------------------------------------
  * NOT part of the reference (openVO is one process on one thread): frame pairs shard across the GPUs of a

@@ -27,7 +27,7 @@ SYMBOLS = [
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints", "vo_download_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_essential5", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
-    "vo_sgbm_last_geometry", "vo_set_stream_hint", "vo_measure_copy", "vo_sgbm_raster_status",
+    "vo_sgbm_last_geometry", "vo_set_stream_hint", "vo_measure_copy", "vo_sgbm_raster_status", "vo_sgbm_sweep_stats",
     "vo_upload_mono", "vo_prefetch_staged_mono", "vo_mono_pair",
     "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_last_error",
     "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
@@ -113,6 +113,7 @@ def lib():
         L.vo_get_timings.argtypes = [vp, vp, vp, ci]
         L.vo_sgbm_last_geometry.argtypes = [vp, vp, vp]
         L.vo_sgbm_raster_status.argtypes = [vp, vp]
+        L.vo_sgbm_sweep_stats.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
         L.vo_measure_copy.argtypes = [vp, ctypes.c_int64, ci, ci, vp]
         L.vo_set_stream_hint.argtypes = [vp, ci]
         L.vo_upload_mono.argtypes = [vp, ci, vp, ci, ci, ci]
@@ -530,6 +531,12 @@ class Context:
         e = ctypes.c_int(0)
         self._ck(self._lib.vo_sgbm_raster_status(self._h, ctypes.byref(e)))
         return e.value
+
+    def sgbm_sweep_stats(self, block=0, n_words=2048):
+        """Control block of the latest aggregation sweep (development aid): see vo_sgbm_sweep_stats."""
+        out = np.zeros(n_words, np.int32)
+        self._ck(self._lib.vo_sgbm_sweep_stats(self._h, int(block), _p(out), n_words))
+        return out
 
     def measure_copy(self, nbytes=0, reps=20, nontemporal=False):
         """GB/s (read + written) of a streaming device copy between two of the context's volumes."""

@@ -1454,6 +1454,7 @@ __global__ void __launch_bounds__(256) k_sgbm_vwta64(const int16_t* __restrict__
 }
 
 #include "sgbm_raster.inc"
+#include "sgbm_diag.inc"
 
 // left-right check of one pixel on the WTA results: disp1 or INVALID
 __device__ __forceinline__ int lr_value(const int16_t* __restrict__ disp1, const int* __restrict__ d2key, const SgbmGeom& g, int x, int y)
@@ -1694,12 +1695,82 @@ static int launch_raster(vo_ctx* ctx, const SgbmGeom& g, const int16_t* Lin, int
     return VO_OK;
 }
 
+
+// ---- diagonal sweep (sgbm_diag.inc) ------------------------------------------------------------------------------------
+template <int NP, bool PAD, int NWC, bool REV, bool WTA>
+static int launch_diag_k(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int16_t* sout, int* ctl)
+{
+    constexpr int UW = 4 * NWC, CW = UW + 2;
+    DiagJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    jobs.n = 1;
+    jobs.nstrips = div_up(g.W1 + g.H - 1, UW);
+    const size_t need = (size_t)jobs.nstrips * (g.H + 1) * 64 * NP * sizeof(uint64_t);
+    const size_t have = (ctx->vol_cells / 4 + 4096) * sizeof(uint64_t);
+    if (!ctx->rs_bnd || need > have) return vo_fail(ctx, VO_E_CAP, "diagonal sweep: boundary buffer too small (%zu > %zu bytes)", need, have);
+    if (ctx->sw_tag == 0) VO_HIP(ctx, hipMemsetAsync(ctx->rs_bnd, 0, have, ctx->stream));   // tags start at 1: no stale granule may match
+    DiagJob& j = jobs.j[0];
+    j.C = ctx->C; j.in1 = in1; j.sout = sout; j.bnd = ctx->rs_bnd; j.aux0 = ctx->ccl_label; j.aux1 = ctx->ccl_runlen;
+    j.tag = ++ctx->sw_tag;
+    j.dbg = ctx->tune_diag_dbg;
+    if (j.tag == 0) j.tag = ++ctx->sw_tag;
+    const size_t lds = (size_t)2 * 2 * CW * g.Dp * 2 + (WTA ? (size_t)NWC * 4 * 2 * g.Dp * 2 : 0) + 64;
+    auto kern = k_sgbm_diag<NP, PAD, NWC, REV, WTA>;
+    static unsigned long long attr_set = 0;     // per instantiation and device: allow more than 64 KB of dynamic LDS
+    if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
+        VO_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set |= 1ull << (ctx->device & 63);
+    }
+    // strips that can be active at the same time: one image row's worth (+ slack for the hand-over between strips)
+    const int wgs = min(jobs.nstrips, div_up(g.W1, UW) + 2);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3((NWC + 1) * 64), lds, ctx->stream, jobs, g, ctl, ctx->dump, ctx->rs_ctl_words / 2);
+    VO_CHECK_LAUNCH(ctx);
+    return VO_OK;
+}
+
+template <int NP, bool REV, bool WTA>
+static int launch_diag(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int16_t* sout, int* ctl)
+{
+    const bool pad = g.D != g.Dp;
+    if constexpr (NP <= 4) {
+        if (ctx->tune_diag_nwc == 15)
+            return pad ? launch_diag_k<NP, true, 15, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 15, REV, WTA>(ctx, g, in1, sout, ctl);
+    }
+    return pad ? launch_diag_k<NP, true, 7, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 7, REV, WTA>(ctx, g, in1, sout, ctl);
+}
+
 template <int NP>
 static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, size_t vol)
 {
     // the last direction of the plan is the top-down vertical one: it runs fused with the WTA
     PathPlan plan = plan_all;
     const bool fuse = ctx->tune_fuse_wta != 0 && g.ur < 100;   // the fused sweep only carries the threshold form of the uniqueness test
+    // Diagonal-sweep schedule: W + E as one stored volume (k_sgbm_we), then NW / N / NE + WTA in ONE pass over C and that
+    // volume (k_sgbm_diag); MODE_HH: a reverse pass first adds SW / S / SE to the W + E volume.  Layout of S: [0] = L_W + L_E,
+    // [1] = MODE_HH: [0] + the three bottom-up directions, last = the E checkpoints of k_sgbm_we (1/8 of a volume).
+    if (fuse && ctx->tune_diag && plan.lpw == 4 && g.W1 % 8 == 0 && g.W1 >= 16) {
+        const bool pad = g.D != g.Dp;
+        const bool hh = plan_all.n_dirs == 8;
+        int rc;
+        {
+            StageTimer t(ctx, VO_T_SGBM_AGG);
+            const int nw = div_up(g.H, 4);
+            int16_t* ck = ctx->S + (size_t)(hh ? 2 : 1) * vol;
+            if (ctx->tune_diag_dbg & 8) {
+            } else if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ck, g, ctx->dump);
+            else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ck, g, ctx->dump);
+            VO_CHECK_LAUNCH(ctx);
+            if (hh && (rc = launch_diag<NP, true, false>(ctx, g, ctx->S, ctx->S + vol, ctx->rs_ctl))) return rc;
+        }
+        {
+            StageTimer t(ctx, VO_T_SGBM_WTA);
+            if (!(ctx->tune_diag_dbg & 16) && (rc = launch_diag<NP, false, true>(ctx, g, hh ? ctx->S + vol : ctx->S, nullptr, ctx->rs_ctl + (hh ? ctx->rs_ctl_words / 2 : 0)))) return rc;
+            hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
+            VO_CHECK_LAUNCH(ctx);
+        }
+        ctx->last_paths = 1;
+        return VO_OK;
+    }
     if (fuse && ctx->tune_raster) {
         // raster scheme: MODE_SGBM = E by the line kernel, then W/NW/N/NE + WTA in one raster pass;
         // MODE_HH = E/SE/S/SW in a reverse raster pass (sum stored), then W/NW/N/NE + WTA in the forward pass
@@ -2014,6 +2085,7 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
     ctx->last_paths = (ctx->tune_fuse_wta && g.ur < 100) ? plan.n_dirs - 1 : plan.n_dirs;   // directions inside the k_sgbm_paths launch
     {
         StageTimer t(ctx, VO_T_SGBM_COST);
+        const int dbg = ctx->tune_diag_dbg;          // development only (VO_DIAG_DEBUG): 4 / 8 / 16 / 32 skip the cost / W+E / diagonal / post stage
         hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
                            ctx->planesL, ctx->planesR, ctx->ccl_size, ctx->rs_ctl, ctx->rs_ctl_words);
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
@@ -2022,6 +2094,8 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
 #define LAUNCH_SWEEP(XT, SW)                                                                                                   \
     hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(div_up(g.W1, XT), div_up(h, TY)), dim3(bx),                            \
                        (size_t)nw * (2 * SW + 1) * XT * 64 * 4, ctx->stream, ctx->planesL, ctx->planesR, g, TY, ctx->C)
+        if (dbg & 4) {
+        } else
         switch (g.SW2) {
             case 0: LAUNCH_SWEEP(8, 0); break;
             case 1: LAUNCH_SWEEP(8, 1); break;
@@ -2056,7 +2130,7 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
         std::swap(ctx->stream, ctx->stream_hi);
         ctx->on_hi = true;
     }
-    {
+    if (!(ctx->tune_diag_dbg & 32)) {
         StageTimer t(ctx, VO_T_SGBM_POST);
         hipLaunchKernelGGL(k_lr_median3, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, ctx->disp_tmp, ctx->ccl_size, g, d_disp);
         if (e.speckleWindow > 0) {

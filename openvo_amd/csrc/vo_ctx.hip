@@ -161,7 +161,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     ctx->S_vols = (ctx->tune_raster && getenv("VO_RASTER_AFTER") == nullptr) ? 1 : 5;
     DALLOC(ctx->S, ctx->vol_cells * ctx->S_vols);
     DALLOC(ctx->rs_bnd, ctx->vol_cells / 4 + 4096);      // uint64 words: one volume's worth of bytes
-    ctx->rs_ctl_words = 2 * (4 + max_h / 4 + 4);
+    ctx->rs_ctl_words = 2 * 2048;                        // two control blocks: {ticket, error, ...} + per-strip timeline of the diagonal sweep
     DALLOC(ctx->rs_ctl, ctx->rs_ctl_words);
     VO_HIP(ctx, hipMemset(ctx->rs_ctl, 0, ctx->rs_ctl_words * sizeof(int)));
     DALLOC(ctx->disp_tmp, npx); DALLOC(ctx->dump, 4096);
@@ -208,6 +208,9 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     if (const char* e19 = getenv("VO_PAIR_HH")) ctx->tune_pair_hh = atoi(e19) ? 1 : 0;
     if (const char* e22 = getenv("VO_VWTA64")) ctx->tune_vwta64 = atoi(e22) ? 1 : 0;
     if (const char* e23 = getenv("VO_VWTA_QUEUED")) ctx->tune_vwta_queued = atoi(e23) == 32 ? 32 : 16;
+    if (const char* e24 = getenv("VO_DIAG")) ctx->tune_diag = atoi(e24) ? 1 : 0;
+    if (const char* e26 = getenv("VO_DIAG_DEBUG")) ctx->tune_diag_dbg = atoi(e26);
+    if (const char* e25 = getenv("VO_DIAG_WAVES")) ctx->tune_diag_nwc = atoi(e25) == 7 ? 7 : 15;
     if (const char* e20 = getenv("VO_BAND")) { int v = atoi(e20); ctx->tune_band = v == 2 ? 2 : (v ? 1 : 0); }
     ctx->band_now = ctx->tune_band == 1;
     if (const char* e17 = getenv("VO_WE_AFTER")) ctx->we_after = atoi(e17);
@@ -494,7 +497,7 @@ static void engine_swap(vo_ctx* ctx, int engine)
     if (engine == 0) return;
     std::swap(ctx->planesL, a.planesL); std::swap(ctx->planesR, a.planesR);
     std::swap(ctx->C, a.C); std::swap(ctx->S, a.S); std::swap(ctx->S_vols, a.S_vols);
-    std::swap(ctx->rs_bnd, a.rs_bnd); std::swap(ctx->rs_ctl, a.rs_ctl);
+    std::swap(ctx->rs_bnd, a.rs_bnd); std::swap(ctx->rs_ctl, a.rs_ctl); std::swap(ctx->sw_tag, a.sw_tag);
     std::swap(ctx->disp_tmp, a.disp_tmp);
     std::swap(ctx->ccl_runlen, a.ccl_runlen); std::swap(ctx->ccl_label, a.ccl_label); std::swap(ctx->ccl_size, a.ccl_size);
     std::swap(ctx->sgbm_done, a.done); std::swap(ctx->sgbm_done_valid, a.done_valid);
@@ -989,6 +992,20 @@ extern "C" int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemp
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *gb_per_s = ms > 0.f ? 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;   // bytes read + bytes written
+    return VO_OK;
+}
+
+// timeline of the latest diagonal sweep in the main workspace (development aid): words [8 + 8 s ..] of control block `block`
+// = {start, end, failed polls, ticks waiting, misses} of strip s in 100 MHz ticks
+extern "C" int vo_sgbm_sweep_stats(vo_ctx* ctx, int block, int32_t* out, int n_words)
+{
+    if (!ctx || !out || block < 0 || block > 1 || n_words <= 0) return vo_fail(ctx, VO_E_ARG, "vo_sgbm_sweep_stats: bad argument");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = vo_synchronize(ctx);
+    if (rc) return rc;
+    const int half = ctx->rs_ctl_words / 2;
+    if (n_words > half) n_words = half;
+    VO_HIP(ctx, hipMemcpy(out, ctx->rs_ctl + block * half, (size_t)n_words * sizeof(int32_t), hipMemcpyDeviceToHost));
     return VO_OK;
 }
 

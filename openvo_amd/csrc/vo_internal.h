@@ -85,6 +85,7 @@ struct vo_ctx {
         int S_vols = 0;
         uint64_t* rs_bnd = nullptr;
         int* rs_ctl = nullptr;
+        uint32_t sw_tag = 0;
         hipEvent_t done = nullptr;
         bool done_valid = false;
         bool ready = false;
@@ -133,6 +134,10 @@ struct vo_ctx {
     uint64_t* rs_bnd = nullptr;    // raster sweep: bottom-row records handed from band to band (one volume's worth)
     int* rs_ctl = nullptr;         // raster sweep: two control blocks {ticket, error, -, -, progress[bands]}
     int rs_ctl_words = 0;
+    uint32_t sw_tag = 0;           // diagonal sweep: launches so far in the current workspace (tag of its boundary granules; 0 = rs_bnd not yet cleared)
+    int tune_diag = 0;             // VO_DIAG: NW / N / NE (+ WTA) as one diagonal sweep over C and the W+E volume (sgbm_diag.inc)
+    int tune_diag_dbg = 0;         // VO_DIAG_DEBUG (development): bit 0 = strips import nothing, bit 1 = export nothing
+    int tune_diag_nwc = 15;        // VO_DIAG_WAVES: compute waves per strip workgroup (7 or 15) for Dp <= 128
     int32_t* ccl_runlen = nullptr;
     int32_t* ccl_label = nullptr;
     int32_t* ccl_size = nullptr;

@@ -1,0 +1,34 @@
+"""Which SGBM stage limits the throughput of the look-ahead engines?  Development aid.
+
+Runs disparity only (no ORB, no pose) for N staged C2 pairs through the engines, once complete and once with each stage
+skipped (VO_DIAG_DEBUG bits: results are then garbage, only the clock counts); the time a stage adds under concurrency is
+the difference.  One process per variant (the knob is read at context creation)."""
+import os, subprocess, sys, time
+
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from openvo_amd import _native
+    from openvo_amd.synth import Corridor
+    c = Corridor("C2")
+    N = 240
+    ctx = _native.Context(0, c.w, c.h, c.D, 500)
+    ctx.set_sgbm(c.sgbm_params(0), 0)
+    ctx.stage_pairs([c.pair(i) for i in range(24)])
+    for i in range(24):
+        ctx.prefetch_staged_pair(i % 24, i % 24, True)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(N):
+        ctx.prefetch_staged_pair(i % 24, i % 24, True)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    print("%-28s %.3f ms/pair  (%.0f pairs/s)" % (os.environ.get("TAG", ""), 1e3 * dt / N, N / dt))
+    sys.exit(0)
+
+for tag, env in (("default schedule", {"VO_DIAG": "0"}), ("diag: complete", {"VO_DIAG": "1"}), ("diag: no cost", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "4"}),
+                 ("diag: no W+E", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "8"}), ("diag: no diagonal", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "16"}),
+                 ("diag: no post", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "32"}), ("diag: only cost", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "56"}),
+                 ("diag: only W+E", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "52"}), ("diag: only diagonal", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "44"}),
+                 ("diag: only post", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "28"})):
+    e = dict(os.environ, TAG=tag, VO_DIAG_WAVES=os.environ.get("VO_DIAG_WAVES", "7"), **env)
+    subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=e, timeout=300)
