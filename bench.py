@@ -54,15 +54,39 @@ def main():
                          "staging + async upload ahead) instead of HBM-resident inputs -- the PCIe-inclusive rate")
     ap.add_argument("--ndisp", type=int, default=0, help="diagnostic: override numDisparities (changes the workload!)")
     ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs the single-thread CPU baseline is timed on (0 = skip both CPU legs)")
-    ap.add_argument("--no-post", action="store_true", help="skip the untimed post-passes (per-stage breakdown, from-host rate)")
+    ap.add_argument("--no-post", action="store_true", help="skip the untimed post-passes (per-stage breakdown, from-host rate, other configs)")
+    ap.add_argument("--no-other", action="store_true", help="skip the C4 / C5 runs attached to the C2 line as `other_configs`")
     args = ap.parse_args()
 
+    from openvo_amd import sharding
+
+    group, device = sharding.init_from_env()
+    if args.workload == "C5":
+        out = bench_c5(args, group, device, args.steps, args.warmup)
+    else:
+        out = bench_stereo(args, group, device, args.workload, args.steps, args.warmup, light=False)
+    if group.rank == 0:
+        if args.workload == "C2" and group.world == 1 and not (args.no_post or args.no_other or args.from_host or args.ndisp):
+            # BASELINE configs 4 and 5 in the same process, after the headline's work is done and its context is closed:
+            # their own complete JSON objects (shorter windows), so that the driver's one command observes them too
+            other = {}
+            for name, fn in (("C4", lambda: bench_stereo(args, group, device, "C4", 12, 4, light=True)),
+                             ("C5", lambda: bench_c5(args, group, device, 20, 4))):
+                try:
+                    other[name] = fn()
+                except Exception as e:                      # a failure here must not cost the headline line
+                    other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["other_configs"] = other
+        print(json.dumps(out))
+    group.barrier()
+    group.close()
+
+
+def bench_stereo(args, group, device, workload, K, W, light):
+    """K timed StereoOdometer.update() steps of one stereo workload (C2, C4, C1 ...) on this rank's GPU; returns the JSON
+    object on rank 0 (None elsewhere).  light = no post-passes, no CPU leg (the attached other_configs)."""
     from openvo_amd import StereoCamera, StereoOdometer, sharding
     from openvo_amd.synth import Corridor
-
-    if args.workload == "C5":
-        return bench_c5(args)
-    group, device = sharding.init_from_env()
     rank, world = group.rank, group.world
     ndev = sharding.device_count()
     masked = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
@@ -74,11 +98,10 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
-    K, W = args.steps, args.warmup
-    c = Corridor(args.workload)
+    c = Corridor(workload)
     # config 4 is the 8-path (MODE_HH) cost-volume stress case; every other workload runs the reference's 5-path default
-    sgbm = c.sgbm_params(mode=1) if args.workload == "C4" else c.sgbm_params()
-    if args.ndisp:
+    sgbm = c.sgbm_params(mode=1) if workload == "C4" else c.sgbm_params()
+    if args.ndisp and not light:
         sgbm["numDisparities"] = args.ndisp
     cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), sgbm, (c.w, c.h), device=device,
                        max_keypoints=ODO_KW["nfeatures"])
@@ -102,13 +125,13 @@ def main():
         odo.update(staged[i], None)
     # HIP events (recorded on the library's stream, resolved after the run) around the dominant
     # kernel only: event packets around every small stage would perturb the throughput measured
-    ctx.enable_timing(not args.no_events, stages=["sgbm_agg"])
+    ctx.enable_timing(not args.no_events, stages=["sgbm_wta"])
     ctx.timings(reset=True)
     rel, acc = [], []
     cam.reset_lookahead()      # nothing computed before the clock starts may be used inside the timed region
     sync_all()
     t0 = time.perf_counter()
-    if args.from_host:
+    if args.from_host and not light:
         before = odo.c_T_w
         for ok in odo.run(frames[W:W + K]):
             acc.append(bool(ok))
@@ -125,17 +148,19 @@ def main():
     group.barrier()
     gc.enable()
     tm = ctx.timings(reset=True)
-    raster_err = ctx.sgbm_raster_status()
+    sweep_err = ctx.sgbm_sweep_status()
+    schedule = {1: "diag", 2: "diag_ragged", 3: "unfused"}.get(ctx.sgbm_last_schedule(), "?")
 
     tb, nb, from_host_rate, copy_gbs = None, 0, None, None
-    if not args.no_post:
+    if not (args.no_post or light):
         # the box's own streaming-copy ceiling: one cost volume's worth of bytes copied between two of the
         # context's volumes, plain and non-temporal, HIP events around 20 repetitions -- untimed, after the measured region
         ctx.synchronize()
         copy_gbs = {"plain": round(ctx.measure_copy(0, 20, False), 1), "nontemporal": round(ctx.measure_copy(0, 20, True), 1)}
-        # per-stage breakdown (information only): a short untimed post-pass with every stage timed and the
-        # look-ahead engines off, i.e. one pair at a time with each kernel alone on the GPU -- the same
-        # condition a rocprofv3 kernel trace imposes (it serialises dispatches)
+    if not args.no_post:
+        # per-stage breakdown: a short untimed post-pass with every stage timed and the look-ahead engines off, i.e. one
+        # pair at a time with each kernel alone on the GPU -- the same condition a rocprofv3 kernel trace imposes (it
+        # serialises dispatches).  The roofline block's top-level figures come from here.
         ctx.enable_timing(True)
         nb = min(8, K)
         la = cam.lookahead
@@ -147,90 +172,95 @@ def main():
         tb = ctx.timings(reset=True)
         ctx.enable_timing(False)
         cam.lookahead = la
-        if not args.from_host and world == 1:
-            # PCIe-inclusive rate (never the reported value): the same pairs handed over as host numpy arrays
-            nh = min(K, 96)
-            hodo = StereoOdometer(cam, **ODO_KW)
-            cam.reset_lookahead()
-            for ok in hodo.run(frames[:min(W, 8)]):
-                pass
-            ctx.synchronize()
-            th = time.perf_counter()
-            for ok in hodo.run(frames[W:W + nh]):
-                pass
-            ctx.synchronize()
-            from_host_rate = nh / (time.perf_counter() - th)
+    if not (args.no_post or light) and not args.from_host and world == 1:
+        # PCIe-inclusive rate (never the reported value): the same pairs handed over as host numpy arrays
+        nh = min(K, 96)
+        hodo = StereoOdometer(cam, **ODO_KW)
+        cam.reset_lookahead()
+        for ok in hodo.run(frames[:min(W, 8)]):
+            pass
+        ctx.synchronize()
+        th = time.perf_counter()
+        for ok in hodo.run(frames[W:W + nh]):
+            pass
+        ctx.synchronize()
+        from_host_rate = nh / (time.perf_counter() - th)
 
     dt_max = group.all_reduce_max(dt)         # max over ranks of the timed region
     # final pose gather (the path's only exchange): 16 float64 + accept flag per frame
     all_rel, all_ok = group.gather_relative(np.array(rel), np.array(acc, np.float64))
 
+    out = None
     if rank == 0:
         total_pairs = K * world
         value = total_pairs / dt_max
         cells, npaths = ctx.sgbm_last_geometry()
-        agg_ms, agg_n = tm["sgbm_agg"]
-        n_launch = agg_n                                               # one aggregation launch per pair
-        per_launch_s = (agg_ms / 1e3) / max(n_launch, 1)
-        alg_bytes = 2.0 * cells * npaths                               # the int16 cost volume read once per path direction
-        achieved = alg_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        P = 8 if workload == "C4" else 5
+        alg_bytes = 2.0 * cells * npaths          # the int16 cost volume read once per direction the kernel covers (3)
+        survey_bytes = 2.0 * cells * (1 + P)      # A_sgbm = 2 B * V * (1 + P) for the whole pair
+        traffic, per_pair = None, None
+        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("sgbm_path_bytes_per_launch")
+                tj = json.load(open(tf))
+                traffic, per_pair = tj.get("dominant_kernel_bytes_per_launch"), tj.get("sgbm_bytes_per_pair")
             except Exception:
-                traffic = None
-        P = 8 if args.workload == "C4" else 5
-        survey_bytes = 2.0 * cells * (1 + P)                            # A_sgbm = 2 B * V * (1 + P)
-        roof = {"bound": "hbm", "kernel": "k_sgbm_paths (+ k_sgbm_we for pairs on the fused W+E schedule): the %d stored aggregation directions; "
-                                          "the top-down vertical one runs fused with the WTA" % npaths,
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "bytes_per_launch": alg_bytes, "launch_us": round(per_launch_s * 1e6, 2), "launches": n_launch,
-                "condition": "achieved/frac: the launch as it runs inside the timed region, several pairs in flight, i.e. it shares "
-                             "HBM with other kernels (a latency under contention, not a throughput)",
-                # whole-job view: SURVEY's algorithmic bytes per pair x pairs/s against the peak
-                "aggregate": {"algorithmic_bytes_per_pair": survey_bytes,
-                              "achieved": round(survey_bytes * value / world / 1e9, 2),
-                              "frac": round(survey_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)}}
+                traffic = per_pair = None
+        roof = {"bound": "hbm",
+                "kernel": "k_sgbm_diag (forward diagonal sweep: NW / N / NE of the %d directions + the W+E volume + winner-take-all; "
+                          "schedule '%s' on every one of the %d timed pairs)" % (P, schedule, K),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "bytes_per_launch": alg_bytes,
+                "schedule_counts": {schedule: K}}
+        if tb is not None:
+            iso_ms, iso_n = tb["sgbm_wta"]
+            iso_s = (iso_ms / 1e3) / max(iso_n, 1)
+            iso_ach = alg_bytes / iso_s / 1e9 if iso_s > 0 else 0.0
+            # top level = the kernel alone on the GPU (post-pass; what a serialising rocprofv3 kernel trace reports)
+            roof.update({"achieved": round(iso_ach, 2), "frac": round(iso_ach / HBM_PEAK_GBS, 5), "launch_us": round(iso_s * 1e6, 2),
+                         "launches": int(iso_n),
+                         "condition": "the launch alone on the GPU (look-ahead off, HIP events on its stream; k_sgbm_fin's ~10 us included): "
+                                      "what profiles/r03_kernel_stats_*.csv reproduces.  The kernel is a latency chain of strips by design -- "
+                                      "it trades its own duration for HBM bytes -- so the job's rate is in `aggregate`"})
+        agg_ms, agg_n = tm["sgbm_wta"]
+        if agg_n:
+            s_in = (agg_ms / 1e3) / agg_n
+            roof["in_stream"] = {"launch_us": round(s_in * 1e6, 2), "launches": int(agg_n), "achieved": round(alg_bytes / s_in / 1e9, 2),
+                                 "note": "the same launch inside the timed region, beside the other pairs' kernels: a latency under contention"}
+        # whole-job view: SURVEY's algorithmic bytes per pair x pairs/s against the peak
+        roof["aggregate"] = {"algorithmic_bytes_per_pair": survey_bytes,
+                             "achieved": round(survey_bytes * value / world / 1e9, 2),
+                             "frac": round(survey_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)}
+        if tb is None:
+            roof.update({"achieved": roof["aggregate"]["achieved"], "frac": roof["aggregate"]["frac"],
+                         "condition": "no post-pass in this run: whole-job algorithmic bytes x pairs/s"})
+        if per_pair:
+            roof["aggregate"]["measured_traffic_bytes_per_pair"] = per_pair
+            roof["aggregate"]["measured_traffic_gb_per_s"] = round(per_pair * value / world / 1e9, 1)
         if copy_gbs is not None:
             ceil = max(copy_gbs.values())
             roof["copy_ceiling"] = {"unit": "GB/s", "bytes_counted": "read + written", **copy_gbs,
                                     "frac_of_peak": round(ceil / HBM_PEAK_GBS, 4)}
-            if traffic is not None and ceil > 0:
-                # what the path kernels really move per pair (PMC, profiles/traffic_*.json) x pairs/s against that ceiling
-                try:
-                    per_pair = json.load(open(tf))["sgbm_bytes_per_pair"]["line"]["bytes_per_pair_corrected"]
-                except Exception:
-                    per_pair = None
-                if per_pair:
-                    roof["aggregate"]["measured_traffic_bytes_per_pair"] = per_pair
-                    roof["aggregate"]["measured_traffic_gb_per_s"] = round(per_pair * value / world / 1e9, 1)
-                    roof["aggregate"]["measured_traffic_frac_of_copy_ceiling"] = round(per_pair * value / world / 1e9 / ceil, 4)
-        if tb is not None:
-            iso_ms, iso_n = tb["sgbm_agg"]
-            iso_s = (iso_ms / 1e3) / max(iso_n, 1)
-            iso_ach = alg_bytes / iso_s / 1e9 if iso_s > 0 else 0.0
-            # alone on the GPU (post-pass, = what a serialising kernel trace reports)
-            roof["alone"] = {"launch_us": round(iso_s * 1e6, 2), "achieved": round(iso_ach, 2), "frac": round(iso_ach / HBM_PEAK_GBS, 5)}
+            if per_pair and ceil > 0:
+                roof["aggregate"]["measured_traffic_frac_of_copy_ceiling"] = round(per_pair * value / world / 1e9 / ceil, 4)
         out = {
-            "metric": "stereo frame-pairs/sec (1280x720)" if args.workload == "C2" else "stereo frame-pairs/sec (%dx%d)" % (c.w, c.h),
+            "metric": "stereo frame-pairs/sec (1280x720)" if workload == "C2" else "stereo frame-pairs/sec (%dx%d)" % (c.w, c.h),
             "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * dt_max / K, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "%s: stereo %dx%d corridor stream, SGBM D=%d %s + ORB %d + "
                                    "Hamming kNN/ratio + 3-D lookup + rigid clique + Umeyama"
-                                   % (args.workload, c.w, c.h, sgbm["numDisparities"], "8-path (MODE_HH)" if args.workload == "C4" else "5-path (MODE_SGBM)",
+                                   % (workload, c.w, c.h, sgbm["numDisparities"], "8-path (MODE_HH)" if workload == "C4" else "5-path (MODE_SGBM)",
                                       ODO_KW["nfeatures"]),
                        "odometer": {k: ODO_KW[k] for k in ("rigidity_threshold", "outlier_threshold", "match_threshold", "min_matches")},
                        "parallelism": "frame-sharded x%d, pose all-gather over %s" % (world, group.transport if world > 1 else "nothing (1 rank)"),
-                       "inputs": "host numpy every step (PCIe-inclusive)" if args.from_host else "resident in HBM",
+                       "inputs": "host numpy every step (PCIe-inclusive)" if args.from_host and not light else "resident in HBM",
                        "deviations": DEVIATIONS},
             "roofline": roof,
             "accepted_frames": int(np.sum(all_ok)), "frames": int(len(all_ok)),
-            "sgbm_raster_error": int(raster_err),
+            "sgbm_sweep_error": int(sweep_err),
         }
+        if world > 1:
+            out["rccl"] = group.describe()        # what the communicator itself reports (ranks, this rank), not a string we made up
         if tb is not None:
             out["stage_ms_per_pair_alone"] = {k: round(v[0] / max(nb + 1, 1), 4) for k, v in tb.items()}
         if from_host_rate is not None:
@@ -243,23 +273,19 @@ def main():
             gt0 = np.linalg.inv(Corridor.gt_pose(first + W - 1))
             err = [np.linalg.norm(poses[i][:3, 3] - (gt0 @ Corridor.gt_pose(first + W + i))[:3, 3]) for i in range(K)]
             out["ate_vs_ground_truth_m"] = round(float(np.sqrt(np.mean(np.square(err)))), 5)
-        if world == 1 and args.cpu_pairs > 0:
+        if world == 1 and args.cpu_pairs > 0 and not light:
             out["cpu_baseline"], out["ate_vs_cpu_m"] = cpu_baseline(c, cam, sgbm, frames, W, min(args.cpu_pairs, K), odo_poses=poses)
-        print(json.dumps(out))
-    group.barrier()
-    group.close()
+    ctx.close()                                   # the next workload of this process gets the whole device
+    return out
 
 
-def bench_c5(args):
+def bench_c5(args, group, device, K_steps, W):
     """BASELINE config 5 (no openVO counterpart): monocular 1920x1080, ORB 8000 keypoints per frame, ~8000 x 8000
     Hamming kNN-2 + ratio, 5000-hypothesis essential-matrix RANSAC -- one MonoOdometer.update per step, frames
     resident in HBM, one host synchronisation per pair.  Not HBM-bound: the roofline block prices the
     two op-counts against the vector-ALU peak instead."""
-    from openvo_amd import sharding
     from openvo_amd.mono import MonoOdometer
     from openvo_amd.synth import Corridor
-    group, device = sharding.init_from_env()
-    K_steps, W = args.steps, args.warmup
     c = Corridor("C5")
     iters, nfeat = 5000, 8000
     Kmat = np.array([[c.f, 0, c.cx], [0, c.f, c.cy], [0, 0, 1.0]])
@@ -288,6 +314,7 @@ def bench_c5(args):
     group.barrier()
     dt = group.all_reduce_max(dt)
     tm = ctx.timings(reset=True)
+    out = None
     if group.rank == 0:
         n_kp = ctx.orb_slot_count(odo._ref[0], nfeat, 0)
         pair_dists = float(n_kp) * n_kp * K_steps       # ~ keypoints^2 Hamming distances (256 bit) per pair
@@ -312,9 +339,8 @@ def bench_c5(args):
                             "stage_ms_per_pair": {k: round(v[0] / K_steps, 4) for k, v in tm.items() if v[0] > 0}},
                "accepted_frames": int(acc), "frames": K_steps, "keypoints_per_frame": int(n_kp),
                "matches_per_pair": int(resid / iters / max(K_steps, 1))}
-        print(json.dumps(out))
-    group.barrier()
-    group.close()
+    odo.close()
+    return out if group.rank == 0 else None
 
 
 # ---- CPU baseline (reported, not the target) ------------------------------------------------------------------

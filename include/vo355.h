@@ -73,11 +73,11 @@ int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
  * asynchronously; later calls that use the slot wait for it on the device.  Lets the next pair's
  * disparity overlap the current pair's ORB / matching / pose kernels. */
 int vo_prefetch_staged_pair(vo_ctx* ctx, int slot, int index, int preprocessed);
-/* scheduling hint for the look-ahead: how many pairs the caller will still submit after the next vo_prefetch_* call
- * (negative = unknown / unbounded).  The library picks, per pair, between two bit-identical aggregation schedules --
- * the low-latency one for pairs near the head or the end of a stream, the low-traffic one (W and E stored as one
- * volume) for pairs that sit behind a queue -- and uses this to recognise the end. */
-int vo_set_stream_hint(vo_ctx* ctx, int pairs_remaining);
+/* look-ahead pairs submitted and not yet waited for or dropped (instrumentation; the reference is synchronous:
+ * stereo_odometer.py:115-117 computes one pair per update() call) */
+int vo_lookahead_depth(vo_ctx* ctx, int* depth_out);
+/* the caller gives up a look-ahead slot without consuming it (a prediction of the next pair that did not come true) */
+int vo_lookahead_drop(vo_ctx* ctx, int slot);
 /* the same from host images -- the caller's decode/ingest step in front of update():
  * copied to pinned staging, uploaded asynchronously on the engine's stream, then as above.  The host
  * buffers are free again when the call returns. */
@@ -231,17 +231,22 @@ enum { VO_T_UPLOAD = 0, VO_T_SGBM_COST, VO_T_SGBM_AGG, VO_T_SGBM_WTA, VO_T_SGBM_
 int vo_enable_timing(vo_ctx* ctx, int on);
 /* accumulated milliseconds and launch counts per stage since the last reset */
 int vo_get_timings(vo_ctx* ctx, double* ms_out /*VO_T_NSTAGES*/, int64_t* launches_out, int reset);
-/* algorithmic cost-volume cells (width1*H*D) of the last vo_sgbm_compute, and the number of path
- * directions aggregated inside its k_sgbm_paths launch (the remaining top-down vertical direction
- * runs fused with the WTA) */
+/* algorithmic cost-volume cells (width1*H*D) of the last vo_sgbm_compute, and the number of path directions its dominant
+ * aggregation kernel covers (3: NW / N / NE inside k_sgbm_diag; all of them for uniquenessRatio >= 100) */
 int vo_sgbm_last_geometry(vo_ctx* ctx, int64_t* cells, int* n_paths);
+/* which aggregation schedule the latest SGBM run of this context took -- it follows from the parameters alone (every
+ * schedule gives the same bits: stereo_camera.py:51 only sees the disparity) */
+enum { VO_SCHED_DIAG = 1,          /* W + E as one volume (k_sgbm_we), NW / N / NE + WTA in the diagonal sweep */
+       VO_SCHED_DIAG_RAGGED = 2,   /* the same with k_sgbm_pair for W + E (width - numDisparities not a multiple of 8) */
+       VO_SCHED_UNFUSED = 3 };     /* uniquenessRatio >= 100: one volume per direction + per-pixel winner search */
+int vo_sgbm_last_schedule(vo_ctx* ctx, int* schedule_out);
 /* measurement aid (SURVEY 8(d) "device-copy ceiling"): `reps` streaming copies of `bytes` (<= one cost volume; 0 = a
  * whole one) between two of the context's volumes, timed with HIP events; *gb_per_s counts bytes read + bytes written.
  * Overwrites the cost volume: call it between, not inside, vo_sgbm_compute / vo_prefetch_pair sequences. */
 int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemporal, double* gb_per_s);
-/* health of the raster aggregation sweeps (synchronises): *error_out != 0 when a wait between rows / bands
+/* health of the diagonal aggregation sweeps (synchronises): *error_out != 0 when a wait between strips
  * ever exceeded its poll limit (the affected disparities are then undefined); sticky until vo_destroy */
-int vo_sgbm_raster_status(vo_ctx* ctx, int* error_out);
+int vo_sgbm_sweep_status(vo_ctx* ctx, int* error_out);
 /* development aid: control block `block` (0 | 1) of the latest aggregation sweep in the main workspace -- word 0 = work items
    taken, word 1 = sticky error, words 8 + 8 s .. = {start, end, failed polls, ticks waiting, misses} of strip s (100 MHz ticks).
    No reference counterpart (stereosgbm.cpp is one sequential pass). */
@@ -260,6 +265,8 @@ int vo_device_count(int* n_out);                       /* HIP devices visible to
 int vo_mgpu_unique_id(uint8_t* id128 /*128 bytes*/);   /* ncclGetUniqueId */
 int vo_mgpu_create(int device, int rank, int world, const uint8_t* id128, vo_mgpu** out);   /* ncclCommInitRank */
 void vo_mgpu_destroy(vo_mgpu* g);
+/* what RCCL itself reports for the communicator: ncclCommCount, ncclCommUserRank, and the device it was created on */
+int vo_mgpu_info(vo_mgpu* g, int* n_ranks, int* user_rank, int* device);
 const char* vo_mgpu_last_error(const vo_mgpu* g);      /* g may be NULL: error of the last failed create / id call */
 /* every rank passes n_frames x 17 float64 (same n_frames on every rank); all_n17 receives world x n_frames x 17
  * in rank order */

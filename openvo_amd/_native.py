@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("VO355_LIB") or os.path.join(_HERE, "libvo355.so")   #
 _CSRC = os.path.join(_HERE, "csrc")
 
 VO_NUM_SLOTS = 28
+SCHED_DIAG, SCHED_DIAG_RAGGED, SCHED_UNFUSED = 1, 2, 3
 T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose")
 
 # every symbol include/vo355.h declares (checked by tests/test_abi.py)
@@ -27,9 +28,9 @@ SYMBOLS = [
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints", "vo_download_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_essential5", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
-    "vo_sgbm_last_geometry", "vo_set_stream_hint", "vo_measure_copy", "vo_sgbm_raster_status", "vo_sgbm_sweep_stats",
+    "vo_sgbm_last_geometry", "vo_lookahead_depth", "vo_lookahead_drop", "vo_sgbm_last_schedule", "vo_measure_copy", "vo_sgbm_sweep_status", "vo_sgbm_sweep_stats",
     "vo_upload_mono", "vo_prefetch_staged_mono", "vo_mono_pair",
-    "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_last_error",
+    "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_info", "vo_mgpu_last_error",
     "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
 ]
 
@@ -48,8 +49,10 @@ def build_native(force=False):
     srcs.append(os.path.join(_HERE, "..", "include", "vo355.h"))
     srcs.append(os.path.join(_HERE, "..", "include", "vo_orb_pattern.inc"))
     newest = max(os.path.getmtime(s) for s in srcs)
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
-        subprocess.check_call(["make", "-C", _CSRC, "-j4"] + (["-B"] if force else []),
+    hooks = os.path.join(_HERE, "libvo355_hooks.so")       # test-only build with the failure-injection hook (tests load it by path)
+    built = os.path.join(_HERE, "libvo355.so")
+    if force or any(not os.path.exists(q) or os.path.getmtime(q) < newest for q in (built, hooks)):
+        subprocess.check_call(["make", "-C", _CSRC, "-j4", "all"] + (["-B"] if force else []),
                               stdout=subprocess.DEVNULL)
     return LIB_PATH
 
@@ -112,10 +115,12 @@ def lib():
         L.vo_enable_timing.argtypes = [vp, ci]
         L.vo_get_timings.argtypes = [vp, vp, vp, ci]
         L.vo_sgbm_last_geometry.argtypes = [vp, vp, vp]
-        L.vo_sgbm_raster_status.argtypes = [vp, vp]
+        L.vo_sgbm_sweep_status.argtypes = [vp, vp]
+        L.vo_lookahead_depth.argtypes = [vp, vp]
+        L.vo_lookahead_drop.argtypes = [vp, ci]
+        L.vo_sgbm_last_schedule.argtypes = [vp, vp]
         L.vo_sgbm_sweep_stats.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
         L.vo_measure_copy.argtypes = [vp, ctypes.c_int64, ci, ci, vp]
-        L.vo_set_stream_hint.argtypes = [vp, ci]
         L.vo_upload_mono.argtypes = [vp, ci, vp, ci, ci, ci]
         L.vo_prefetch_staged_mono.argtypes = [vp, ci, ci, ci]
         L.vo_mono_pair.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, ci, vp, vp, vp, vp, vp, ci]
@@ -233,8 +238,20 @@ class Context:
         self._ck(self._lib.vo_load_staged_pair(self._h, slot, int(index), int(bool(preprocessed))))
         return self.staged_shape
 
-    def set_stream_hint(self, pairs_remaining):
-        self._ck(self._lib.vo_set_stream_hint(self._h, int(pairs_remaining)))
+    def lookahead_depth(self):
+        """Look-ahead pairs submitted and not yet waited for or dropped."""
+        d = ctypes.c_int(0)
+        self._ck(self._lib.vo_lookahead_depth(self._h, ctypes.byref(d)))
+        return d.value
+
+    def lookahead_drop(self, slot):
+        self._ck(self._lib.vo_lookahead_drop(self._h, int(slot)))
+
+    def sgbm_last_schedule(self):
+        """SCHED_* of the latest SGBM run of this context."""
+        d = ctypes.c_int(0)
+        self._ck(self._lib.vo_sgbm_last_schedule(self._h, ctypes.byref(d)))
+        return d.value
 
     def prefetch_staged_pair(self, slot, index, preprocessed):
         self._ck(self._lib.vo_prefetch_staged_pair(self._h, slot, int(index), int(bool(preprocessed))))
@@ -526,10 +543,10 @@ class Context:
         self._ck(self._lib.vo_get_timings(self._h, _p(ms), _p(n), int(reset)))
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(T_STAGES)}
 
-    def sgbm_raster_status(self):
-        """0 = every raster sweep so far completed its hand-offs; non-zero = a wait timed out (sticky)."""
+    def sgbm_sweep_status(self):
+        """0 = every diagonal sweep so far completed its hand-offs; non-zero = a wait timed out (sticky)."""
         e = ctypes.c_int(0)
-        self._ck(self._lib.vo_sgbm_raster_status(self._h, ctypes.byref(e)))
+        self._ck(self._lib.vo_sgbm_sweep_status(self._h, ctypes.byref(e)))
         return e.value
 
     def sgbm_sweep_stats(self, block=0, n_words=2048):

@@ -1361,12 +1361,7 @@ static int pose_alt_prepare(vo_ctx* ctx, int k)
     vo_ctx::PoseAlt& p = ctx->pose_alt[k];
     if (p.ready) return VO_OK;
     const size_t cap = (size_t)ctx->kp_cap;
-    if (ctx->tune_prio) {
-        int lo = 0, hi = 0;
-        VO_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        VO_HIP(ctx, hipStreamCreateWithPriority(&p.stream, hipStreamNonBlocking, hi));
-    } else
-        VO_HIP(ctx, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    VO_HIP(ctx, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     VO_HIP(ctx, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     VO_HIP(ctx, hipHostMalloc(&p.result, 1024, hipHostMallocDefault));
     VO_HIP(ctx, hipMalloc((void**)&p.m_idx, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.m_dist, cap * 8 + 256));
@@ -1428,6 +1423,11 @@ extern "C" int vo_pose_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
         if (!rc && hipEventRecord(p.done, ctx->stream) != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
     }
     if (rc) return rc;
+    // both slots are read on this alternate's stream until p.done: whoever refills one of them waits for it first
+    for (FrameSlot* f : { &a, &b }) {
+        if (f->readers[0] == p.done || f->readers[1] == p.done) continue;
+        f->readers[f->readers[0] ? 1 : 0] = p.done;
+    }
     p.busy = true; p.slot_a = slot_a; p.slot_b = slot_b;
     p.params[0] = ratio; p.params[1] = min_matches; p.params[2] = rigidity_thr; p.params[3] = outlier_thr;
     ctx->pose_next = (k + 1) % vo_ctx::N_POSE_ALT;

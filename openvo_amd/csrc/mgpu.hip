@@ -22,6 +22,8 @@ struct RcclApi {
     int (*GetUniqueId)(ncclUniqueId*) = nullptr;
     int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int*) = nullptr;
+    int (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -46,6 +48,8 @@ static bool rccl_load()
     BIND(GetUniqueId, "ncclGetUniqueId");
     BIND(CommInitRank, "ncclCommInitRank");
     BIND(CommDestroy, "ncclCommDestroy");
+    BIND(CommCount, "ncclCommCount");
+    BIND(CommUserRank, "ncclCommUserRank");
     BIND(AllGather, "ncclAllGather");
     BIND(AllReduce, "ncclAllReduce");
     BIND(GetErrorString, "ncclGetErrorString");
@@ -135,6 +139,16 @@ extern "C" void vo_mgpu_destroy(vo_mgpu* g)
     if (g->d_recv) (void)hipFree(g->d_recv);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
+}
+
+// what the communicator itself reports: number of ranks and this process's rank in it (ncclCommCount / ncclCommUserRank)
+extern "C" int vo_mgpu_info(vo_mgpu* g, int* n_ranks, int* user_rank, int* device)
+{
+    if (!g || !n_ranks || !user_rank || !device) return mg_fail(g, VO_E_ARG, "vo_mgpu_info: bad argument");
+    MG_NCCL(g, g_rccl.CommCount(g->comm, n_ranks));
+    MG_NCCL(g, g_rccl.CommUserRank(g->comm, user_rank));
+    *device = g->device;
+    return VO_OK;
 }
 
 static int mg_reserve(vo_mgpu* g, size_t n)

@@ -119,9 +119,6 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h)
     // new image size (rare: once per size).  What those extractions produced stays valid.
     for (int k = 0; k < vo_ctx::MAX_ENGINES; k++)
         if (ctx->la_stream[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream[k]));
-    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++)
-        if (ctx->la_stream_hi[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream_hi[k]));
-    if (ctx->stream_hi) VO_HIP(ctx, hipStreamSynchronize(ctx->stream_hi));
     for (int k = 0; k < vo_ctx::N_POSE_ALT; k++)
         if (ctx->pose_alt[k].stream) VO_HIP(ctx, hipStreamSynchronize(ctx->pose_alt[k].stream));
     VO_HIP(ctx, hipMemcpyAsync(ctx->rs_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, ctx->stream));

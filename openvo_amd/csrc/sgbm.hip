@@ -7,25 +7,25 @@
 //   planesL[y][x]        2 x u32  : (u,u0,u1) bytes of the x-Sobel channel, then of the raw channel
 //   planesR[k][y][p]     u32      : plane k of (v,v0,v1)x2, packed as value(p) | value(p-1) << 16
 //   C[y][x1][Dp]         int16    : block cost (+P2), d fastest, Dp = D rounded up to 32, x1 = x - minX1
-//   L[dir][y][x1][Dp]    int16    : one aggregated volume per STORED path direction (all but the top-down
-//                                   vertical one, which only ever lives in registers)
-// Kernels
+//   S[0][y][x1][Dp]      int16    : L_W + L_E, the only aggregated volume MODE_SGBM ever stores
+//   S[1]                          : MODE_HH: S[0] + the three bottom-up directions;  S[2]: checkpoints of the W + E kernel
+//   sw_bnd               u64      : boundary granules of the diagonal sweep [strip][H + 1][NP][64]
+// Kernels (the schedule: launch_agg below)
 //   k_sgbm_planes  prefilter + Birchfield-Tomasi half-pixel bounds (elementwise)
 //   k_sgbm_cost_sweep  BT pixel cost + (2*SW2+1)^2 box sum; one lane = one disparity PAIR in packed
 //                  int16x2 math; right-image planes travel through DPP lane-shift chains, the horizontal
 //                  window slides in registers, the vertical one through an LDS ring; writes C once
-//   k_sgbm_paths   every stored path direction in one launch.  A scan line lives in one 16-lane DPP row
-//                  (each lane holds Dp/16 consecutive disparities in packed registers), so a wave
-//                  advances 4 independent lines; neighbours d-1/d+1 come from row_shr/row_shl
-//                  (row ends are the MAX_COST sentinels for free), the min over d is a 4-step
-//                  row_ror all-reduce.  Reads C once per direction, writes that direction's L with
-//                  non-temporal stores (single use; C must stay cached for the other directions).
-//   k_sgbm_vwta    the top-down vertical direction fused with the WTA: a wave walks 4 columns, per row it
-//                  reads C and the stored L volumes, advances its own path in registers, sums, picks the
-//                  first minimum and tests uniqueness; leaves a 2-word record per pixel
+//   k_sgbm_we      W and E as ONE stored volume: a scan line lives in one 16-lane DPP row (each lane holds
+//                  Dp/16 consecutive disparities in packed registers), so a wave advances 4 image rows;
+//                  neighbours d-1/d+1 come from row_shr/row_shl (row ends are the MAX_COST sentinels for
+//                  free), the min over d is a 4-step row_ror all-reduce; E is kept as checkpoints every 8th
+//                  column and recomputed per segment while W passes (k_sgbm_pair: the same for any line length)
+//   k_sgbm_diag    (sgbm_diag.inc) NW / N / NE computed together in skewed columns, added to the W + E volume,
+//                  winner-take-all on the total: leaves a 2-word record per pixel.  MODE_HH: a reverse pass
+//                  first adds SW / S / SE to the volume.  No direction of these three is ever stored
 //   k_sgbm_fin     records -> sub-pixel disp1 + disp2 candidates via atomicMin on (cost, scan order) keys
-//   k_sgbm_wta     unfused fallback (VO_FUSE_WTA=0, uniquenessRatio >= 100): per pixel (16 lanes) S = sat-sum
-//                  of all L volumes, same winner logic inline
+//   k_sgbm_paths + k_sgbm_wta   uniquenessRatio >= 100 only (no threshold form of the uniqueness test): one
+//                  stored volume per direction, per pixel (16 lanes) S = sat-sum of all of them, winner logic inline
 //   k_lr_median3   left-right consistency check evaluated inside medianBlur(3)
 //   k_ccl_*        filterSpeckles (run-based union-find labelling)
 #include "vo_internal.h"
@@ -70,6 +70,8 @@ __device__ __forceinline__ uint32_t row_min_u32(uint32_t v)
 
 struct SgbmGeom {
     int W, H, W1, D, Dp, minD, minX1, P1, P2, ur, d12, ftzero, invalid16, SW2;
+    uint32_t urM, urAdd;   // ceil(a / (100 - ur)) = mulhi(a + urAdd, urM) for a < 2^22: urM = ceil(2^32 / (100 - ur)), urAdd = 99 - ur
+                           // (100 - ur == 1: urM = 2^32 - 1, urAdd = 1)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -98,14 +100,14 @@ __device__ __forceinline__ void chan_bounds(const uint8_t* img, int W, int H, in
 
 __global__ void k_sgbm_planes(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
                               int ft, uint32_t* __restrict__ PL, uint32_t* __restrict__ PR, int* __restrict__ d2key,
-                              int* __restrict__ rs_ctl, int rs_ctl_words)
+                              int* __restrict__ sw_ctl, int sw_ctl_words)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    // the raster sweeps' band tickets and progress counters of this run start at zero (word 1 of each of the
+    // the diagonal sweeps' work-item tickets and timelines of this run start at zero (word 1 of each of the
     // two control blocks is its sticky error flag and is left alone)
     if (y == 0 && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < rs_ctl_words; i += blockDim.x)
-            if ((i % (rs_ctl_words / 2)) != 1) rs_ctl[i] = 0;
+        for (int i = threadIdx.x; i < sw_ctl_words; i += blockDim.x)
+            if ((i % (sw_ctl_words / 2)) != 1) sw_ctl[i] = 0;
     if (x >= W) return;
     size_t i = (size_t)y * W + x, plane = (size_t)W * H;
     d2key[i] = D2_EMPTY;   // the disp2 candidates of this run start empty (saves a fill launch before the WTA)
@@ -369,37 +371,14 @@ __device__ __forceinline__ LV<NP> lv_fill(uint32_t x)
 
 // L(d) = C(d) + min(Lp(d), Lp(d-1)+P1, Lp(d+1)+P1, delta) - delta  (C carries +P2, delta = minLp + P2)
 // padreg bit k set: register k lies beyond D and must stay at MAX_COST
-template <int NP>
-__device__ __forceinline__ LV<NP> path_step(const LV<NP>& Cp, const LV<NP>& Lp, uint32_t delta2, uint32_t P1_2, unsigned padreg)
+// the d-1 / d+1 windows are shared between neighbouring registers: window j = (L[2j-1], L[2j]); a scan line (or a pixel) is
+// one 16-lane DPP row, so the row ends take the MAX_COST sentinels for free
+template <int NP, bool PAD>
+__device__ __forceinline__ LV<NP> path_step2(const LV<NP>& Cp, const LV<NP>& Lp, uint32_t delta2, uint32_t P1_2, unsigned padreg)
 {
     LV<NP> out;
     const uint32_t prev_hi = DPP(MAXC2, Lp.r[NP - 1], ROW_SHR1);  // lane-1's last register; row start keeps the sentinel
     const uint32_t next_lo = DPP(MAXC2, Lp.r[0], ROW_SHL1);       // lane+1's first register; row end keeps the sentinel
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-        const uint32_t left = k == 0 ? prev_hi : Lp.r[k - 1];
-        const uint32_t right = k == NP - 1 ? next_lo : Lp.r[k + 1];
-        const uint32_t dm1 = __builtin_amdgcn_alignbit(Lp.r[k], left, 16);   // (L[d-1], L[d])
-        const uint32_t dp1 = __builtin_amdgcn_alignbit(right, Lp.r[k], 16);  // (L[d+1], L[d+2])
-        const uint32_t m = pk_min(pk_min(Lp.r[k], delta2), pk_min(pk_add_sat(dm1, P1_2), pk_add_sat(dp1, P1_2)));
-        const uint32_t L = pk_sub(pk_add(Cp.r[k], m), delta2);
-        out.r[k] = ((padreg >> k) & 1u) ? MAXC2 : L;
-    }
-    return out;
-}
-
-// the same step with the d-1 / d+1 windows shared between neighbouring registers: window j = (L[2j-1], L[2j]);
-// LPL = lanes per scan line (16: a DPP row; 8: half a row, the group's first / last lane take the sentinels explicitly)
-template <int NP, bool PAD, int LPL = 16>
-__device__ __forceinline__ LV<NP> path_step2(const LV<NP>& Cp, const LV<NP>& Lp, uint32_t delta2, uint32_t P1_2, unsigned padreg, int l = 0)
-{
-    LV<NP> out;
-    uint32_t prev_hi = DPP(MAXC2, Lp.r[NP - 1], ROW_SHR1);
-    uint32_t next_lo = DPP(MAXC2, Lp.r[0], ROW_SHL1);
-    if constexpr (LPL == 8) {
-        prev_hi = l == 0 ? MAXC2 : prev_hi;
-        next_lo = l == 7 ? MAXC2 : next_lo;
-    }
     uint32_t w[NP + 1];
     w[0] = __builtin_amdgcn_alignbit(Lp.r[0], prev_hi, 16);
 #pragma unroll
@@ -413,15 +392,6 @@ __device__ __forceinline__ LV<NP> path_step2(const LV<NP>& Cp, const LV<NP>& Lp,
         out.r[k] = (PAD && ((padreg >> k) & 1u)) ? MAXC2 : L;
     }
     return out;
-}
-
-// all-reduce (min, unsigned) inside each group of 8 lanes
-__device__ __forceinline__ uint32_t half_min_u32(uint32_t v)
-{
-    v = min(v, DPP(0xFFFFFFFFu, v, 0xB1));    // quad_perm [1,0,3,2]
-    v = min(v, DPP(0xFFFFFFFFu, v, 0x4E));    // quad_perm [2,3,0,1]
-    v = min(v, DPP(0xFFFFFFFFu, v, 0x141));   // row_half_mirror
-    return v;
 }
 
 template <int NP>
@@ -438,26 +408,22 @@ struct PathPlan {
     int n_dirs;
     int sx[VO_MAX_DIRS], sy[VO_MAX_DIRS];
     int nlines[VO_MAX_DIRS];
-    int first_wave[VO_MAX_DIRS + 1];  // prefix sum of ceil(nlines / lines per wave)
-    int lpw;                          // lines per wave (host side: 4 = 16 lanes per line, 8 = 8 lanes per line)
+    int first_wave[VO_MAX_DIRS + 1];  // prefix sum of ceil(nlines / 4): four scan lines per wave
 };
 
-// NP = registers per lane (2*NP disparities), LPL = lanes per scan line (LPL * 2 * NP = Dp), 64 / LPL lines per wave.
-// Fewer lanes per line = more disparities per lane: the per-step fixed work (addresses, the min all-reduce, delta) is
-// spread over more cells and the launch has half the waves.
-// (TAG only makes the launch of the fused W+E schedule -- NW and NE alone, 1 -- a kernel name of its own in profiles)
-template <int NP, int PF, int LPL = 16, bool PAD = true, int TAG = 0>
+// One stored volume per direction: only the schedule without the threshold form of the uniqueness test (uniquenessRatio >= 100)
+// still runs it.  NP = registers per lane (2 NP disparities), 16 lanes per scan line, four lines per wave.
+template <int NP, int PF, bool PAD>
 __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ C, int16_t* __restrict__ Lbase, size_t vol,
                                                    SgbmGeom g, PathPlan plan, int16_t* __restrict__ dump)
 {
-    constexpr int LPW = 64 / LPL;
-    const int lane = threadIdx.x & 63, row = lane / LPL, l16 = lane % LPL;
+    const int lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wave >= plan.first_wave[plan.n_dirs]) return;
     int dir = 0;
     while (dir + 1 < plan.n_dirs && wave >= plan.first_wave[dir + 1]) dir++;
     const int sx = plan.sx[dir], sy = plan.sy[dir];
-    const int line = (wave - plan.first_wave[dir]) * LPW + row;
+    const int line = (wave - plan.first_wave[dir]) * 4 + row;
     const int W1 = g.W1, H = g.H;
     int x0 = 0, y0 = 0, n = 0;
     if (line < plan.nlines[dir]) {
@@ -474,7 +440,7 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
     }
     int nmax = 0;
 #pragma unroll
-    for (int r = 0; r < LPW; r++) nmax = max(nmax, __builtin_amdgcn_readlane(n, r * LPL));
+    for (int r = 0; r < 4; r++) nmax = max(nmax, __builtin_amdgcn_readlane(n, r * 16));
 
     const int d0 = l16 * 2 * NP;
     unsigned padreg = 0;
@@ -507,8 +473,6 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
     int16_t* pst = lp;                                              // cell of the current step
     // (the trip count is rounded up to whole groups of PF steps -- the surplus steps only feed the sink --
     // so that the unrolled body is straight-line code and the waits stay partial)
-    // (TAG 2) every line of this wave starts on the image's top row
-    const bool alltop = __builtin_amdgcn_readfirstlane((int)(__ballot(n > 0 && y0 != 0) == 0ull)) != 0;
     for (int i0 = 0; i0 < nmax; i0 += PF) {
 #pragma unroll
         for (int k = 0; k < PF; k++) {
@@ -516,25 +480,11 @@ __global__ void __launch_bounds__(256) k_sgbm_paths(const int16_t* __restrict__ 
             const LV<NP> Cv = cbuf[k];
             cbuf[k] = lv_load<NP>(pld);
             pld += (i + PF < last) ? stride : 0;
-            const LV<NP> L = path_step2<NP, PAD, LPL>(Cv, Lp, delta2, P1_2, padreg, l16);
-            const uint32_t lm = lane_min16<NP>(L);
-            const uint32_t mn = LPL == 8 ? half_min_u32(lm) : row_min_u32(lm);
-            delta2 = pk_add(pk_rep((int)mn), P2_2);
+            const LV<NP> L = path_step2<NP, PAD>(Cv, Lp, delta2, P1_2, padreg);
+            delta2 = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(L))), P2_2);
             Lp = L;
-            if constexpr (TAG == 2) {
-                // band schedule: only the last row of every 8-row band is kept, as rk[dir][y >> 3][x][d] (`vol` carries the
-                // number of bands; every direction of such a launch steps one row down per step).  Lines that start on
-                // the top row (all of N, most of NW / NE) are in row i at step i: for a wave made of such lines the
-                // store is the unrolled body's 8th step and nothing else; the other waves store every step, mostly
-                // into the dump area.
-                const int yy = y0 + i, xx = x0 + i * sx;
-                const bool keep = i < n && (yy & 7) == 7;
-                if (!alltop || (PF == 8 && k == 7))
-                    lv_store<NP>(keep ? Lbase + (((size_t)dir * vol + (size_t)(yy >> 3)) * W1 + xx) * g.Dp + d0 : sink, L);
-            } else {
-                lv_store_nt<NP>(i < n ? pst : sink, L);
-                pst += stride;
-            }
+            lv_store_nt<NP>(i < n ? pst : sink, L);
+            pst += stride;
         }
     }
 }
@@ -798,13 +748,9 @@ __device__ __forceinline__ void wta_core(const LV<NP>& S, const SgbmGeom& g, int
     bool viol = false;
     const int ur100 = 100 - g.ur;
     if (THR) {
-        // exact ceil(minS*100 / ur100): float estimate (operands < 2^24) + integer fix-up
+        // exact ceil(minS*100 / ur100) by a multiply-high with the reciprocal the host prepared (a < 2^22, ur100 <= 100)
         const int a = minS * 100;
-        int T = (int)((float)a * __builtin_amdgcn_rcpf((float)ur100));
-        T += (T * ur100 < a);
-        T += (T * ur100 < a);
-        T -= ((T - 1) * ur100 >= a);
-        T -= ((T - 1) * ur100 >= a);
+        const int T = (int)__umulhi((unsigned)a + g.urAdd, g.urM);
         const uint32_t T2 = pk_rep(min(T, 32768));   // S <= 32767: a larger T changes nothing
         // bit e of m8: this lane's element e (d = d0 + e) lies within one of the winner -- never a violation
         const int t = min(max(best + 4 - d0, 0), 31);
@@ -928,532 +874,6 @@ __global__ void __launch_bounds__(256) k_sgbm_wta(const int16_t* __restrict__ Lb
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// band schedule (MODE_SGBM): the three top-down directions are never stored as volumes
-// ---------------------------------------------------------------------------------------
-// N, NW and NE of a row depend on the row above only.  A pre-pass (k_sgbm_paths<..., 2>) walks their lines as usual
-// but keeps only the last row of every 8-row band (3/8 of a volume).  This kernel then finishes the job band by band,
-// in parallel: a workgroup owns TW columns of one band, loads the checkpoint row above it for TW + 16 columns, and
-// recomputes the three directions row by row in LDS -- the columns it needs shrink by one on each side per row, so the
-// 8-column halos are all it ever reads from its neighbours' territory -- adding the stored W+E volume and running the
-// winner-take-all for its own columns.  Nothing here waits for another workgroup, and the final stage has no 720-step
-// serial sweep any more.  16 lanes per pixel, 16 pixels per 256-thread workgroup per step; two state buffers (row above /
-// this row) of 3 directions x (TW + 16) columns x Dp cells in LDS; columns outside the image hold the border state
-// (zeros), whose minimum is 0, so "predecessor outside" needs no special case.
-template <int NP, bool PAD, int TW>
-__global__ void __launch_bounds__(256) k_sgbm_band(const int16_t* __restrict__ C, const int16_t* __restrict__ Swe, const int16_t* __restrict__ rk,
-                                                  int nbands, SgbmGeom g, int16_t* __restrict__ disp1, int* __restrict__ d2key)
-{
-    constexpr int CW = TW + 16;
-    extern __shared__ __attribute__((aligned(16))) int16_t s_band[];   // [2][3][CW][Dp] state, then [16][Dp] WTA scratch
-    const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;   // 16 pixel groups
-    const int Dp = g.Dp, W1 = g.W1, H = g.H;
-    const int band = blockIdx.y, x0 = blockIdx.x * TW, x1 = min(x0 + TW, W1);
-    const int base = x0 - 8;                                             // image column of state column 0
-    const int d0 = l16 * 2 * NP;
-    unsigned padreg = 0;
-    if constexpr (PAD) {
-#pragma unroll
-        for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
-    }
-    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
-    LV<NP> border;
-#pragma unroll
-    for (int k = 0; k < NP; k++) border.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;
-    const size_t bufsz = (size_t)3 * CW * Dp;
-    int16_t* myS = s_band + 2 * bufsz + (size_t)grp * Dp;
-    // state of the row above the band: the checkpoints of band - 1 (border for the top band and outside the image);
-    // the other buffer starts as border everywhere so that out-of-image columns read as border on every row
-    for (int it = grp; it < 3 * CW; it += 16) {
-        const int dir = it / CW, col = it % CW, x = base + col;
-        LV<NP> v = border;
-        if (band > 0 && x >= 0 && x < W1) v = lv_load<NP>(rk + (((size_t)dir * nbands + (band - 1)) * W1 + x) * Dp + d0);
-        lv_store<NP>(s_band + ((size_t)dir * CW + col) * Dp + d0, v);
-        lv_store<NP>(s_band + bufsz + ((size_t)dir * CW + col) * Dp + d0, border);
-    }
-    __syncthreads();
-    int cur = 1;
-    for (int r = 0; r < 8; r++) {
-        const int y = band * 8 + r;
-        if (y >= H) break;                                               // (uniform)
-        const int lo = max(0, x0 - (7 - r)), hi = min(W1, x1 + (7 - r));
-        const int16_t* prev = s_band + (size_t)(cur ^ 1) * bufsz;
-        int16_t* now = s_band + (size_t)cur * bufsz;
-        const size_t rowoff = (size_t)y * W1;
-        // this group's columns of the row: lo + grp, + 16, + 32 ... (at most (TW + 14 + 15) / 16 of them)
-        constexpr int MAXI = (TW + 14 + 15) / 16;
-        LV<NP> cv[MAXI], sw[MAXI];
-#pragma unroll
-        for (int q = 0; q < MAXI; q++) {
-            const int c = min(lo + grp + 16 * q, W1 - 1);
-            cv[q] = lv_load<NP>(C + (rowoff + c) * Dp + d0);
-            const int cs = (c >= x0 && c < x1) ? c : x0;               // halo columns have no pixel to decide: re-read a cached cell
-            sw[q] = lv_load_nt<NP>(Swe + (rowoff + cs) * Dp + d0);
-        }
-#pragma unroll
-        for (int q = 0; q < MAXI; q++) {
-            const int c = lo + grp + 16 * q;
-            const bool act = c < hi;                                     // lane-group uniform
-            const int cc = act ? c - base : 8;                           // (inactive groups replay a harmless column into scratch-free registers)
-            LV<NP> S = sw[q];
-#pragma unroll
-            for (int dir = 0; dir < 3; dir++) {
-                const int pc = cc + (dir == 1 ? -1 : (dir == 2 ? 1 : 0));   // predecessor column: N same, NW left, NE right
-                const LV<NP> Lp = lv_load<NP>(prev + ((size_t)dir * CW + pc) * Dp + d0);
-                const uint32_t delta2 = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(Lp))), P2_2);
-                const LV<NP> L = path_step2<NP, PAD>(cv[q], Lp, delta2, P1_2, padreg);
-                if (act) lv_store<NP>(now + ((size_t)dir * CW + cc) * Dp + d0, L);
-#pragma unroll
-                for (int k = 0; k < NP; k++) S.r[k] = pk_add_sat(S.r[k], L.r[k]);
-            }
-            const bool live = act && c >= x0 && c < x1;
-            if (__ballot(live) != 0ull)                                  // (wave-uniform: halo-only waves skip the winner search)
-                wta_pixel<NP, PAD, true>(S, g, lane, live, c, y, myS, disp1, d2key);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-}
-
-// Last aggregation direction (predecessor (x, y-1), swept top to bottom) fused with the WTA: the wave
-// walks 4 adjacent image columns; per row it reads C and the other directions' L volumes, advances
-// its own path in registers, sums and picks the winner -- this direction's L is never written and
-// the WTA needs no pass of its own.
-template <int NP, int NV, bool PAD>
-__global__ void __launch_bounds__(256) k_sgbm_vwta(const int16_t* __restrict__ C, const int16_t* __restrict__ Lbase, size_t vol,
-                                                  SgbmGeom g, int* __restrict__ aux0, int* __restrict__ aux1)
-{
-    extern __shared__ int16_t s_S[];  // [blockDim/16][2][Dp]
-    const int lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int x1 = wave * 4 + row;
-    if (wave * 4 >= g.W1) return;
-    const bool live = x1 < g.W1;
-    const int xc = live ? x1 : g.W1 - 1;          // dead rows shadow a valid column, never store
-    const int d0 = l16 * 2 * NP;
-    unsigned padreg = 0;
-    if (PAD) {
-#pragma unroll
-        for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
-    }
-    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
-    const size_t stride = (size_t)g.W1 * g.Dp;
-    const uint32_t start = (uint32_t)(xc * g.Dp + d0);   // lane offset inside one image row of the volume
-    int16_t* myS = s_S + (size_t)(threadIdx.x >> 4) * 2 * g.Dp;   // two rows of S: this step's and the previous one's
-    LV<NP> Lp;
-#pragma unroll
-    for (int k = 0; k < NP; k++) Lp.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;
-    uint32_t delta2 = P2_2;
-    // The winner's record is written one step late: its two neighbour costs come back from LDS while
-    // the next row is being computed, so the sweep never waits on the LDS round trip.
-    const bool writer = live && l16 == 0;
-    uint32_t aoff = (uint32_t)(x1 + g.minX1);   // record index of the PREVIOUS row's pixel
-    int prec = -1, pbest = 0, par = 0;
-    // rows in flight: one lone wave per SIMD must cover the ~2 us HBM latency by itself, within ~128 VGPRs
-    constexpr int RPS = NP * (NV + 1);   // registers per prefetched row
-    constexpr int PF = RPS <= 20 ? 6 : RPS <= 32 ? 4 : RPS <= 48 ? 3 : 2;
-    LV<NP> cbuf[PF], lbuf[PF][NV];
-    // wave-uniform row pointers advance by one row per step; the lane part stays a 32-bit offset
-    const int16_t* rowC = C;
-    const int16_t* rowL = Lbase;
-#pragma unroll
-    for (int k = 0; k < PF; k++) {
-        if (k < g.H) {
-            cbuf[k] = lv_load_nt<NP>(rowC + start);
-#pragma unroll
-            for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
-            rowC += stride;
-            rowL += stride;
-        }
-    }
-    for (int y0 = 0; y0 < g.H; y0 += PF) {
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const int y = y0 + k;
-            if (y < g.H) {
-                const LV<NP> Cv = cbuf[k];
-                LV<NP> S = lbuf[k][0];
-#pragma unroll
-                for (int v = 1; v < NV; v++)
-#pragma unroll
-                    for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], lbuf[k][v].r[q]);
-                if (y + PF < g.H) {
-                    cbuf[k] = lv_load_nt<NP>(rowC + start);
-#pragma unroll
-                    for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
-                    rowC += stride;
-                    rowL += stride;
-                }
-                const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
-                const int16_t* prevS = myS + (par ^ 1) * g.Dp;
-                const uint32_t nb = ((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1];
-                const LV<NP> L = path_step<NP>(Cv, Lp, delta2, P1_2, padreg);
-                const uint32_t mn = row_min_u32(lane_min16<NP>(L));
-                delta2 = pk_add(pk_rep((int)mn), P2_2);
-                Lp = L;
-#pragma unroll
-                for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], L.r[q]);
-                int minS, best;
-                bool row_viol;
-                wta_core<NP, PAD, true>(S, g, lane, minS, best, row_viol);
-                lv_store<NP>(myS + par * g.Dp + d0, S);
-                if (writer && y > 0) {
-                    aux0[aoff] = prec;
-                    aux1[aoff] = (int)nb;
-                }
-                if (y > 0) aoff += (uint32_t)g.W;
-                prec = row_viol ? -1 : ((minS << 8) | best);
-                pbest = best;
-                par ^= 1;
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    {   // the last row's record
-        const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
-        const int16_t* prevS = myS + (par ^ 1) * g.Dp;
-        if (writer) {
-            aux0[aoff] = prec;
-            aux1[aoff] = (int)(((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// the same fused sweep with 32 lanes per column (two columns per wave): twice the waves -- 1152 columns make 576
-// waves instead of 288 on 1024 SIMDs -- and half the packed registers per lane, i.e. half the instructions on each
-// wave's serial chain (the counters say this sweep is issue-bound on its lone wave per SIMD: VALU busy 61 %, parked
-// 24 %; profiles/r02_occupancy_c2.csv).  The d-1 / d+1 neighbours cross the two 16-lane DPP rows of a column with
-// wave_shr / wave_shl (column edges patched to MAX_COST), the 32-lane minimum closes with one v_permlane16_swap.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t grp32_min_u32(uint32_t v)
-{
-    v = row_min_u32(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // rows (0,1) and (2,3) exchange
-    return min(r[0], r[1]);
-}
-
-template <int NP>
-__device__ __forceinline__ LV<NP> path_step32(const LV<NP>& Cp, const LV<NP>& Lp, uint32_t delta2, uint32_t P1_2, unsigned padreg, int l32)
-{
-    LV<NP> out;
-    uint32_t prev_hi = DPP(MAXC2, Lp.r[NP - 1], 0x138);   // wave_shr:1 -- lane-1's last register
-    uint32_t next_lo = DPP(MAXC2, Lp.r[0], 0x130);        // wave_shl:1 -- lane+1's first register
-    prev_hi = l32 == 0 ? MAXC2 : prev_hi;                 // the column's first / last lane see the MAX_COST sentinels
-    next_lo = l32 == 31 ? MAXC2 : next_lo;
-    uint32_t w[NP + 1];
-    w[0] = __builtin_amdgcn_alignbit(Lp.r[0], prev_hi, 16);
-#pragma unroll
-    for (int k = 1; k < NP; k++) w[k] = __builtin_amdgcn_alignbit(Lp.r[k], Lp.r[k - 1], 16);
-    w[NP] = __builtin_amdgcn_alignbit(next_lo, Lp.r[NP - 1], 16);
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-        const uint32_t nb = pk_add_sat(pk_min(w[k], w[k + 1]), P1_2);
-        const uint32_t m = pk_min(pk_min(Lp.r[k], delta2), nb);
-        const uint32_t L = pk_sub(pk_add(Cp.r[k], m), delta2);
-        out.r[k] = ((padreg >> k) & 1u) ? MAXC2 : L;
-    }
-    return out;
-}
-
-// wta_core for a 32-lane column group (threshold form of the uniqueness test only)
-template <int NP, bool PAD>
-__device__ __forceinline__ void wta_core32(const LV<NP>& S, const SgbmGeom& g, int lane, int& minS, int& best, bool& grp_viol)
-{
-    const int l32 = lane & 31, d0 = l32 * 2 * NP;
-    uint32_t key = 0xFFFFFFFFu;
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-        const int d = d0 + 2 * k;
-        if (!PAD || d < g.D) {
-            const uint32_t k0 = ((S.r[k] & 0xFFFFu) << 8) | (uint32_t)d;
-            const uint32_t k1 = ((S.r[k] >> 16) << 8) | (uint32_t)(d + 1);
-            key = min(key, min(k0, k1));
-        }
-    }
-    key = grp32_min_u32(key);
-    minS = (int)(key >> 8);
-    best = (int)(key & 255u);
-    const int ur100 = 100 - g.ur;
-    const int a = minS * 100;
-    int T = (int)((float)a * __builtin_amdgcn_rcpf((float)ur100));
-    T += (T * ur100 < a);
-    T += (T * ur100 < a);
-    T -= ((T - 1) * ur100 >= a);
-    T -= ((T - 1) * ur100 >= a);
-    const uint32_t T2 = pk_rep(min(T, 32768));
-    const int t = min(max(best + 4 - d0, 0), 31);
-    uint32_t m8 = ((7u << t) >> 5) & ((1u << (2 * NP)) - 1u);
-    if (PAD) {
-        const int npad = min(max(d0 + 2 * NP - g.D, 0), 2 * NP);
-        m8 |= (0xFFFFu << (2 * NP - npad)) & ((1u << (2 * NP)) - 1u);
-    }
-    uint32_t any = 0;
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * k, 1);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * k + 1, 1);
-        const uint32_t excl = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
-        any |= pk_sub_sat_u(T2, S.r[k]) & ~excl;
-    }
-    const unsigned long long bal = __ballot(any != 0);
-    grp_viol = ((bal >> (lane & 32)) & 0xFFFFFFFFull) != 0ull;
-}
-
-template <int NP, int NV, bool PAD>
-__global__ void __launch_bounds__(256) k_sgbm_vwta32(const int16_t* __restrict__ C, const int16_t* __restrict__ Lbase, size_t vol,
-                                                    SgbmGeom g, int* __restrict__ aux0, int* __restrict__ aux1)
-{
-    extern __shared__ int16_t s_S[];  // [blockDim/32][2][Dp]
-    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int x1 = wave * 2 + half;
-    if (wave * 2 >= g.W1) return;
-    const bool live = x1 < g.W1;
-    const int xc = live ? x1 : g.W1 - 1;
-    const int d0 = l32 * 2 * NP;
-    unsigned padreg = 0;
-    if (PAD) {
-#pragma unroll
-        for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
-    }
-    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
-    const size_t stride = (size_t)g.W1 * g.Dp;
-    const uint32_t start = (uint32_t)(xc * g.Dp + d0);
-    int16_t* myS = s_S + (size_t)(threadIdx.x >> 5) * 2 * g.Dp;
-    LV<NP> Lp;
-#pragma unroll
-    for (int k = 0; k < NP; k++) Lp.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;
-    uint32_t delta2 = P2_2;
-    const bool writer = live && l32 == 0;
-    uint32_t aoff = (uint32_t)(x1 + g.minX1);
-    int prec = -1, pbest = 0, par = 0;
-    constexpr int RPS = NP * (NV + 1);
-    constexpr int PF = RPS <= 10 ? 8 : RPS <= 20 ? 6 : RPS <= 32 ? 4 : 3;
-    LV<NP> cbuf[PF], lbuf[PF][NV];
-    const int16_t* rowC = C;
-    const int16_t* rowL = Lbase;
-#pragma unroll
-    for (int k = 0; k < PF; k++) {
-        if (k < g.H) {
-            cbuf[k] = lv_load_nt<NP>(rowC + start);
-#pragma unroll
-            for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
-            rowC += stride;
-            rowL += stride;
-        }
-    }
-    for (int y0 = 0; y0 < g.H; y0 += PF) {
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const int y = y0 + k;
-            if (y < g.H) {
-                const LV<NP> Cv = cbuf[k];
-                LV<NP> S = lbuf[k][0];
-#pragma unroll
-                for (int v = 1; v < NV; v++)
-#pragma unroll
-                    for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], lbuf[k][v].r[q]);
-                if (y + PF < g.H) {
-                    cbuf[k] = lv_load_nt<NP>(rowC + start);
-#pragma unroll
-                    for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
-                    rowC += stride;
-                    rowL += stride;
-                }
-                const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
-                const int16_t* prevS = myS + (par ^ 1) * g.Dp;
-                const uint32_t nb = ((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1];
-                const LV<NP> L = path_step32<NP>(Cv, Lp, delta2, P1_2, padreg, l32);
-                const uint32_t mn = grp32_min_u32(lane_min16<NP>(L));
-                delta2 = pk_add(pk_rep((int)mn), P2_2);
-                Lp = L;
-#pragma unroll
-                for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], L.r[q]);
-                int minS, best;
-                bool viol;
-                wta_core32<NP, PAD>(S, g, lane, minS, best, viol);
-                lv_store<NP>(myS + par * g.Dp + d0, S);
-                if (writer && y > 0) {
-                    aux0[aoff] = prec;
-                    aux1[aoff] = (int)nb;
-                }
-                if (y > 0) aoff += (uint32_t)g.W;
-                prec = viol ? -1 : ((minS << 8) | best);
-                pbest = best;
-                par ^= 1;
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    {
-        const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
-        const int16_t* prevS = myS + (par ^ 1) * g.Dp;
-        if (writer) {
-            aux0[aoff] = prec;
-            aux1[aoff] = (int)(((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1]);
-        }
-    }
-}
-
-// ---- the same fused sweep with 64 lanes per column (one column per wave): Dp / 128 registers per lane -------------
-// 1152 waves at C2 instead of 576 (more than one per SIMD), each step shorter; only for Dp = 128 or 256.
-__device__ __forceinline__ uint32_t wave64_min_u32(uint32_t v)
-{
-    v = row_min_u32(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // rows (0,1) and (2,3) exchange
-    v = min(r[0], r[1]);
-    const auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // halves exchange
-    return min(q[0], q[1]);
-}
-
-template <int NP>
-__device__ __forceinline__ LV<NP> path_step64(const LV<NP>& Cp, const LV<NP>& Lp, uint32_t delta2, uint32_t P1_2, int lane)
-{
-    LV<NP> out;
-    uint32_t prev_hi = DPP(MAXC2, Lp.r[NP - 1], 0x138);   // wave_shr:1
-    uint32_t next_lo = DPP(MAXC2, Lp.r[0], 0x130);        // wave_shl:1
-    prev_hi = lane == 0 ? MAXC2 : prev_hi;
-    next_lo = lane == 63 ? MAXC2 : next_lo;
-    uint32_t w[NP + 1];
-    w[0] = __builtin_amdgcn_alignbit(Lp.r[0], prev_hi, 16);
-#pragma unroll
-    for (int k = 1; k < NP; k++) w[k] = __builtin_amdgcn_alignbit(Lp.r[k], Lp.r[k - 1], 16);
-    w[NP] = __builtin_amdgcn_alignbit(next_lo, Lp.r[NP - 1], 16);
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-        const uint32_t nb = pk_add_sat(pk_min(w[k], w[k + 1]), P1_2);
-        const uint32_t m = pk_min(pk_min(Lp.r[k], delta2), nb);
-        out.r[k] = pk_sub(pk_add(Cp.r[k], m), delta2);
-    }
-    return out;
-}
-
-// winner + uniqueness verdict of one pixel held by the whole wave (threshold form; no padded disparities: D = Dp)
-template <int NP>
-__device__ __forceinline__ void wta_core64(const LV<NP>& S, const SgbmGeom& g, int lane, int& minS, int& best, bool& viol)
-{
-    const int d0 = lane * 2 * NP;
-    uint32_t key = 0xFFFFFFFFu;
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-        const int d = d0 + 2 * k;
-        const uint32_t k0 = ((S.r[k] & 0xFFFFu) << 8) | (uint32_t)d;
-        const uint32_t k1 = ((S.r[k] >> 16) << 8) | (uint32_t)(d + 1);
-        key = min(key, min(k0, k1));
-    }
-    key = wave64_min_u32(key);
-    minS = (int)(key >> 8);
-    best = (int)(key & 255u);
-    const int ur100 = 100 - g.ur;
-    const int a = minS * 100;
-    int T = (int)((float)a * __builtin_amdgcn_rcpf((float)ur100));
-    T += (T * ur100 < a);
-    T += (T * ur100 < a);
-    T -= ((T - 1) * ur100 >= a);
-    T -= ((T - 1) * ur100 >= a);
-    const uint32_t T2 = pk_rep(min(T, 32768));
-    const int t = min(max(best + 4 - d0, 0), 31);
-    const uint32_t m8 = ((7u << t) >> 5) & ((1u << (2 * NP)) - 1u);       // bits of this lane's disparities within best +- 1
-    uint32_t any = 0;
-#pragma unroll
-    for (int k = 0; k < NP; k++) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * k, 1);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * k + 1, 1);
-        const uint32_t excl = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
-        any |= pk_sub_sat_u(T2, S.r[k]) & ~excl;
-    }
-    viol = __ballot(any != 0) != 0ull;
-}
-
-template <int NP, int NV>
-__global__ void __launch_bounds__(256) k_sgbm_vwta64(const int16_t* __restrict__ C, const int16_t* __restrict__ Lbase, size_t vol,
-                                                    SgbmGeom g, int* __restrict__ aux0, int* __restrict__ aux1)
-{
-    extern __shared__ int16_t s_S[];  // [blockDim/64][2][Dp]
-    const int lane = threadIdx.x & 63;
-    const int x1 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (x1 >= g.W1) return;
-    const int d0 = lane * 2 * NP;
-    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
-    const size_t stride = (size_t)g.W1 * g.Dp;
-    const uint32_t start = (uint32_t)(x1 * g.Dp + d0);
-    int16_t* myS = s_S + (size_t)(threadIdx.x >> 6) * 2 * g.Dp;
-    LV<NP> Lp;
-#pragma unroll
-    for (int k = 0; k < NP; k++) Lp.r[k] = 0u;
-    uint32_t delta2 = P2_2;
-    const bool writer = lane == 0;
-    uint32_t aoff = (uint32_t)(x1 + g.minX1);
-    int prec = -1, pbest = 0, par = 0;
-    constexpr int PF = 8;
-    LV<NP> cbuf[PF], lbuf[PF][NV];
-    const int16_t* rowC = C;
-    const int16_t* rowL = Lbase;
-#pragma unroll
-    for (int k = 0; k < PF; k++) {
-        if (k < g.H) {
-            cbuf[k] = lv_load_nt<NP>(rowC + start);
-#pragma unroll
-            for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
-            rowC += stride;
-            rowL += stride;
-        }
-    }
-    for (int y0 = 0; y0 < g.H; y0 += PF) {
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const int y = y0 + k;
-            if (y < g.H) {
-                const LV<NP> Cv = cbuf[k];
-                LV<NP> S = lbuf[k][0];
-#pragma unroll
-                for (int v = 1; v < NV; v++)
-#pragma unroll
-                    for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], lbuf[k][v].r[q]);
-                if (y + PF < g.H) {
-                    cbuf[k] = lv_load_nt<NP>(rowC + start);
-#pragma unroll
-                    for (int v = 0; v < NV; v++) lbuf[k][v] = lv_load_nt<NP>(rowL + (size_t)v * vol + start);
-                    rowC += stride;
-                    rowL += stride;
-                }
-                const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
-                const int16_t* prevS = myS + (par ^ 1) * g.Dp;
-                const uint32_t nb = ((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1];
-                const LV<NP> L = path_step64<NP>(Cv, Lp, delta2, P1_2, lane);
-                const uint32_t mn = wave64_min_u32(lane_min16<NP>(L));
-                delta2 = pk_add(pk_rep((int)mn), P2_2);
-                Lp = L;
-#pragma unroll
-                for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(S.r[q], L.r[q]);
-                int minS, best;
-                bool viol;
-                wta_core64<NP>(S, g, lane, minS, best, viol);
-                lv_store<NP>(myS + par * g.Dp + d0, S);
-                if (writer && y > 0) {
-                    aux0[aoff] = prec;
-                    aux1[aoff] = (int)nb;
-                }
-                if (y > 0) aoff += (uint32_t)g.W;
-                prec = viol ? -1 : ((minS << 8) | best);
-                pbest = best;
-                par ^= 1;
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    {
-        const int i0 = max(pbest - 1, 0), i1 = min(pbest + 1, g.Dp - 1);
-        const int16_t* prevS = myS + (par ^ 1) * g.Dp;
-        if (writer) {
-            aux0[aoff] = prec;
-            aux1[aoff] = (int)(((uint32_t)(uint16_t)prevS[i0] << 16) | (uint32_t)(uint16_t)prevS[i1]);
-        }
-    }
-}
-
-#include "sgbm_raster.inc"
 #include "sgbm_diag.inc"
 
 // left-right check of one pixel on the WTA results: disp1 or INVALID
@@ -1649,52 +1069,35 @@ __global__ void k_ccl_apply(int16_t* __restrict__ img, int n, int newVal, int ma
 // ---------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------
-static PathPlan make_plan(const SgbmGeom& g, int mode, int lpw)
+static PathPlan make_plan(const SgbmGeom& g, int mode)
 {
     // steps = negated predecessor offsets.  MODE_SGBM predecessors: (x-1,y) (x+1,y) (x-1,y-1) (x,y-1)
     // (x+1,y-1); MODE_HH adds (x-1,y+1) (x,y+1) (x+1,y+1).  Longest lines first.
     static const int sx5[] = { 1, -1, 1, -1, 0 }, sy5[] = { 0, 0, 1, 1, 1 };
-    static const int sx8[] = { 1, -1, 1, -1, 1, -1, 0, 0 }, sy8[] = { 0, 0, 1, 1, -1, -1, -1, 1 };   // (0,+1) last: fused with the WTA
+    static const int sx8[] = { 1, -1, 1, -1, 1, -1, 0, 0 }, sy8[] = { 0, 0, 1, 1, -1, -1, -1, 1 };
     PathPlan p;
-    p.lpw = lpw;
     p.n_dirs = mode == 1 ? 8 : 5;
     p.first_wave[0] = 0;
     for (int k = 0; k < p.n_dirs; k++) {
         p.sx[k] = mode == 1 ? sx8[k] : sx5[k];
         p.sy[k] = mode == 1 ? sy8[k] : sy5[k];
         p.nlines[k] = p.sy[k] == 0 ? g.H : (p.sx[k] == 0 ? g.W1 : g.W1 + g.H - 1);
-        p.first_wave[k + 1] = p.first_wave[k] + div_up(p.nlines[k], lpw);
+        p.first_wave[k + 1] = p.first_wave[k] + div_up(p.nlines[k], 4);
     }
     for (int k = p.n_dirs; k < VO_MAX_DIRS; k++) { p.sx[k] = p.sy[k] = p.nlines[k] = 0; p.first_wave[k + 1] = p.first_wave[p.n_dirs]; }
     return p;
 }
 
-// rows per band (= compute waves per workgroup) of the raster sweep: two waves per SIMD while the ring fits in LDS
-static inline int raster_rows(int NP)
+// the current workspace's S holds at least `vols` volumes (grown once; the default covers the fused schedule)
+static int ensure_S(vo_ctx* ctx, int vols)
 {
-    if (const char* e = getenv("VO_RASTER_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 8) return v; }
-    return NP <= 4 ? 8 : 4;
-}
-
-template <int NP, bool PAD, bool REV, bool HASIN, bool WTA>
-static int launch_raster(vo_ctx* ctx, const SgbmGeom& g, const int16_t* Lin, int16_t* Sout, int* ctl)
-{
-    const int R = raster_rows(NP), nbands = div_up(g.H, R);
-    const size_t lds = (size_t)(R + 1) * RS_RING * NP * 256 + (size_t)(R + 1) * RS_RING * 16 + (size_t)32 * 4 +
-                       (size_t)R * 2 * 4 * g.Dp * 2;
-    if (!ctx->rs_bnd) VO_HIP(ctx, hipMalloc((void**)&ctx->rs_bnd, (ctx->vol_cells * 3 / 8 + 4096) * 8 + 256));   // first use in this workspace
-    auto kern = k_sgbm_raster<NP, PAD, REV, HASIN, WTA>;
-    static unsigned long long attr_set = 0;     // per instantiation and device: allow more than 64 KB of dynamic LDS
-    if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
-        VO_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set |= 1ull << (ctx->device & 63);
-    }
-    hipLaunchKernelGGL(kern, dim3(nbands < ctx->tune_raster_wgs ? nbands : ctx->tune_raster_wgs), dim3((R + 2) * 64), lds, ctx->stream, ctx->C, Lin, Sout, ctx->rs_bnd, ctl, g, R, nbands,
-                       ctx->ccl_label, ctx->ccl_runlen, ctx->dump);
-    VO_CHECK_LAUNCH(ctx);
+    if (ctx->S_vols >= vols) return VO_OK;
+    if (ctx->S) (void)hipFree(ctx->S);
+    ctx->S = nullptr; ctx->S_vols = 0;
+    VO_HIP(ctx, hipMalloc((void**)&ctx->S, ctx->vol_cells * sizeof(int16_t) * vols + 256));
+    ctx->S_vols = vols;
     return VO_OK;
 }
-
 
 // ---- diagonal sweep (sgbm_diag.inc) ------------------------------------------------------------------------------------
 template <int NP, bool PAD, int NWC, bool REV, bool WTA>
@@ -1705,15 +1108,22 @@ static int launch_diag_k(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int
     memset(&jobs, 0, sizeof(jobs));
     jobs.n = 1;
     jobs.nstrips = div_up(g.W1 + g.H - 1, UW);
+    // boundary granules of this workspace: [strip][H + 1 rows][NP][64 lanes] x 8 bytes, allocated (and cleared: tags start at
+    // 1, no stale granule may match) when first needed or outgrown
     const size_t need = (size_t)jobs.nstrips * (g.H + 1) * 64 * NP * sizeof(uint64_t);
-    const size_t have = (ctx->vol_cells / 4 + 4096) * sizeof(uint64_t);
-    if (!ctx->rs_bnd || need > have) return vo_fail(ctx, VO_E_CAP, "diagonal sweep: boundary buffer too small (%zu > %zu bytes)", need, have);
-    if (ctx->sw_tag == 0) VO_HIP(ctx, hipMemsetAsync(ctx->rs_bnd, 0, have, ctx->stream));   // tags start at 1: no stale granule may match
+    if (need > ctx->sw_bnd_bytes) {
+        if (ctx->sw_bnd) (void)hipFree(ctx->sw_bnd);
+        ctx->sw_bnd = nullptr; ctx->sw_bnd_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->sw_bnd, need + 256));
+        ctx->sw_bnd_bytes = need;
+        VO_HIP(ctx, hipMemsetAsync(ctx->sw_bnd, 0, need, ctx->stream));
+    }
     DiagJob& j = jobs.j[0];
-    j.C = ctx->C; j.in1 = in1; j.sout = sout; j.bnd = ctx->rs_bnd; j.aux0 = ctx->ccl_label; j.aux1 = ctx->ccl_runlen;
+    j.C = ctx->C; j.in1 = in1; j.sout = sout; j.bnd = ctx->sw_bnd; j.aux0 = ctx->ccl_label; j.aux1 = ctx->ccl_runlen;
     j.tag = ++ctx->sw_tag;
-    j.dbg = ctx->tune_diag_dbg;
     if (j.tag == 0) j.tag = ++ctx->sw_tag;
+    j.sink = ctx->max_w * ctx->max_h;          // every pixel array is allocated with 256 spare bytes
+    j.dbg = ctx->tune_diag_dbg;
     const size_t lds = (size_t)2 * 2 * CW * g.Dp * 2 + (WTA ? (size_t)NWC * 4 * 2 * g.Dp * 2 : 0) + 64;
     auto kern = k_sgbm_diag<NP, PAD, NWC, REV, WTA>;
     static unsigned long long attr_set = 0;     // per instantiation and device: allow more than 64 KB of dynamic LDS
@@ -1722,8 +1132,8 @@ static int launch_diag_k(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int
         attr_set |= 1ull << (ctx->device & 63);
     }
     // strips that can be active at the same time: one image row's worth (+ slack for the hand-over between strips)
-    const int wgs = min(jobs.nstrips, div_up(g.W1, UW) + 2);
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3((NWC + 1) * 64), lds, ctx->stream, jobs, g, ctl, ctx->dump, ctx->rs_ctl_words / 2);
+    const int wgs = ctx->tune_diag_wgs > 0 ? min(jobs.nstrips, ctx->tune_diag_wgs) : min(jobs.nstrips, div_up(g.W1, UW) + 2);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3((NWC + 1) * 64), lds, ctx->stream, jobs, g, ctl, ctx->dump, ctx->sw_ctl_words / 2);
     VO_CHECK_LAUNCH(ctx);
     return VO_OK;
 }
@@ -1739,310 +1149,87 @@ static int launch_diag(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int16
     return pad ? launch_diag_k<NP, true, 7, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 7, REV, WTA>(ctx, g, in1, sout, ctl);
 }
 
+// Aggregation + winner-take-all of one pair.  The schedule follows from the parameters alone (nothing per pair, no
+// context member is written):
+//   uniquenessRatio < 100 (the reference's own setting is 10):
+//     1. W + E as ONE stored volume: k_sgbm_we (rows in 8-column segments; width a multiple of 8), otherwise k_sgbm_pair
+//        (any width: steps past a line's end are computed and discarded)
+//     2. MODE_HH: a reverse diagonal sweep adds SW / S / SE to that volume
+//     3. the forward diagonal sweep: NW / N / NE + the volume -> winner-take-all records; k_sgbm_fin turns them into
+//        disp1 + the disp2 candidates
+//     volume passes over HBM: C written 1, W+E 3.25, (MODE_HH reverse 3,) forward 2 = 6.25 / 9.25
+//   uniquenessRatio >= 100 (the threshold form of the uniqueness test does not exist): every direction stored by
+//     k_sgbm_paths, per-pixel winner search over all of them (k_sgbm_wta)
+// Layout of S (fused): [0] = L_W + L_E, [1] = MODE_HH: [0] + the three bottom-up directions, [2] = checkpoints of step 1.
 template <int NP>
-static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan_all, size_t vol)
+static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size_t vol)
 {
-    // the last direction of the plan is the top-down vertical one: it runs fused with the WTA
-    PathPlan plan = plan_all;
-    const bool fuse = ctx->tune_fuse_wta != 0 && g.ur < 100;   // the fused sweep only carries the threshold form of the uniqueness test
-    // Diagonal-sweep schedule: W + E as one stored volume (k_sgbm_we), then NW / N / NE + WTA in ONE pass over C and that
-    // volume (k_sgbm_diag); MODE_HH: a reverse pass first adds SW / S / SE to the W + E volume.  Layout of S: [0] = L_W + L_E,
-    // [1] = MODE_HH: [0] + the three bottom-up directions, last = the E checkpoints of k_sgbm_we (1/8 of a volume).
-    if (fuse && ctx->tune_diag && plan.lpw == 4 && g.W1 % 8 == 0 && g.W1 >= 16) {
-        const bool pad = g.D != g.Dp;
-        const bool hh = plan_all.n_dirs == 8;
-        int rc;
+    const bool pad = g.D != g.Dp;
+    const bool hh = plan.n_dirs == 8;
+    int rc;
+    if (g.ur < 100) {
+        if ((rc = ensure_S(ctx, 3))) return rc;
+        int16_t* const Swe = ctx->S;
+        int16_t* const Srev = ctx->S + vol;
+        int16_t* const ck = ctx->S + 2 * vol;
+        int* const ctlA = ctx->sw_ctl;
+        int* const ctlB = ctx->sw_ctl + ctx->sw_ctl_words / 2;
         {
             StageTimer t(ctx, VO_T_SGBM_AGG);
-            const int nw = div_up(g.H, 4);
-            int16_t* ck = ctx->S + (size_t)(hh ? 2 : 1) * vol;
             if (ctx->tune_diag_dbg & 8) {
-            } else if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ck, g, ctx->dump);
-            else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ck, g, ctx->dump);
-            VO_CHECK_LAUNCH(ctx);
-            if (hh && (rc = launch_diag<NP, true, false>(ctx, g, ctx->S, ctx->S + vol, ctx->rs_ctl))) return rc;
-        }
-        {
-            StageTimer t(ctx, VO_T_SGBM_WTA);
-            if (!(ctx->tune_diag_dbg & 16) && (rc = launch_diag<NP, false, true>(ctx, g, hh ? ctx->S + vol : ctx->S, nullptr, ctx->rs_ctl + (hh ? ctx->rs_ctl_words / 2 : 0)))) return rc;
-            hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
-            VO_CHECK_LAUNCH(ctx);
-        }
-        ctx->last_paths = 1;
-        return VO_OK;
-    }
-    if (fuse && ctx->tune_raster) {
-        // raster scheme: MODE_SGBM = E by the line kernel, then W/NW/N/NE + WTA in one raster pass;
-        // MODE_HH = E/SE/S/SW in a reverse raster pass (sum stored), then W/NW/N/NE + WTA in the forward pass
-        int* ctlA = ctx->rs_ctl;
-        int* ctlB = ctx->rs_ctl + ctx->rs_ctl_words / 2;
-        int rc;
-        {
-            StageTimer t(ctx, VO_T_SGBM_AGG);
-            if (plan_all.n_dirs == 5) {
-                PathPlan pe = plan_all;
-                pe.n_dirs = 1;
-                pe.sx[0] = -1; pe.sy[0] = 0; pe.nlines[0] = g.H;
-                pe.first_wave[0] = 0;
-                for (int k = 0; k < VO_MAX_DIRS; k++) pe.first_wave[k + 1] = div_up(g.H, 4);
-                const int nwaves = pe.first_wave[1];
-                if (NP <= 4)
-                    hipLaunchKernelGGL((k_sgbm_paths<NP, 8>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, pe, ctx->dump);
-                else
-                    hipLaunchKernelGGL((k_sgbm_paths<NP, 4>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, pe, ctx->dump);
-                VO_CHECK_LAUNCH(ctx);
+            } else if (g.W1 % 8 == 0 && g.W1 >= 16) {
+                const int nw = div_up(g.H, 4);
+                if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, Swe, ck, g, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, Swe, ck, g, ctx->dump);
             } else {
-                if (g.D == g.Dp) rc = launch_raster<NP, false, true, false, false>(ctx, g, nullptr, ctx->S, ctlA);
-                else rc = launch_raster<NP, true, true, false, false>(ctx, g, nullptr, ctx->S, ctlA);
-                if (rc) return rc;
+                PathPlan pp = plan;                                  // the W / E pair alone: one line per image row
+                pp.n_dirs = 1;
+                pp.sx[0] = 1; pp.sy[0] = 0; pp.nlines[0] = g.H;
+                pp.first_wave[0] = 0;
+                for (int k = 0; k < VO_MAX_DIRS; k++) pp.first_wave[k + 1] = div_up(g.H, 4);
+                for (int k = 1; k < VO_MAX_DIRS; k++) pp.sx[k] = pp.sy[k] = pp.nlines[k] = 0;
+                const int nwp = pp.first_wave[1];
+                if (pad) hipLaunchKernelGGL((k_sgbm_pair<NP, true>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->C, Swe, ck, vol, g, pp, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_pair<NP, false>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->C, Swe, ck, vol, g, pp, ctx->dump);
             }
+            VO_CHECK_LAUNCH(ctx);
+            if (hh && (rc = launch_diag<NP, true, false>(ctx, g, Swe, Srev, ctlA))) return rc;
         }
         {
             StageTimer t(ctx, VO_T_SGBM_WTA);
-            if (g.D == g.Dp) rc = launch_raster<NP, false, false, true, true>(ctx, g, ctx->S, nullptr, ctlB);
-            else rc = launch_raster<NP, true, false, true, true>(ctx, g, ctx->S, nullptr, ctlB);
-            if (rc) return rc;
+            if (!(ctx->tune_diag_dbg & 16) && (rc = launch_diag<NP, false, true>(ctx, g, hh ? Srev : Swe, nullptr, hh ? ctlB : ctlA))) return rc;
             hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
             VO_CHECK_LAUNCH(ctx);
         }
-        ctx->last_paths = plan_all.n_dirs == 5 ? 1 : 0;
+        ctx->last_paths = 3;
+        ctx->last_schedule = (g.W1 % 8 == 0 && g.W1 >= 16) ? VO_SCHED_DIAG : VO_SCHED_DIAG_RAGGED;
         return VO_OK;
     }
-    if (plan_all.n_dirs > ctx->S_vols) {
-        // the line-per-direction scheme stores one volume per direction; grow once
-        if (ctx->S) (void)hipFree(ctx->S);
-        ctx->S = nullptr; ctx->S_vols = 0;
-        VO_HIP(ctx, hipMalloc((void**)&ctx->S, ctx->vol_cells * sizeof(int16_t) * plan_all.n_dirs + 256));
-        ctx->S_vols = plan_all.n_dirs;
-    }
-    if (fuse) {
-        plan.n_dirs = plan_all.n_dirs - 1;
-        for (int k = plan.n_dirs; k < VO_MAX_DIRS; k++) plan.first_wave[k + 1] = plan.first_wave[plan.n_dirs];
-    }
-    // VO_WE_FUSE: W and E as one stored volume (k_sgbm_we), then the other stored directions by the line kernel (NW, NE;
-    // MODE_HH: also the three bottom-up ones), then the fused sweep over ND + 1 volumes.
-    // Layout of S: [0] = L_W + L_E, [1 .. ND] = the other directions, [ND + 1] = the E checkpoints (1/8 of a volume).
-    // Band schedule (MODE_SGBM, VO_BAND): W + E as one volume, row checkpoints of N / NW / NE, then the band kernel.
-    // Layout of S: [0] = L_W + L_E, [1] = row checkpoints (3/8 of a volume), [3] = the E checkpoints of k_sgbm_we.
-    if constexpr (NP <= 4) {
-        if (fuse && ctx->band_now && plan.lpw == 4 && plan_all.n_dirs == 5 && g.W1 % 8 == 0 && g.W1 >= 16 && g.H >= 8) {
-            const bool pad = g.D != g.Dp;
-            const int nb = div_up(g.H, 8);
-            constexpr int TW = 32;
-            const size_t lds = ((size_t)2 * 3 * (TW + 16) + 16) * g.Dp * sizeof(int16_t);
-            static unsigned long long attr_done = 0;   // per device
-            if (!((attr_done >> (ctx->device & 63)) & 1ull)) {
-                VO_HIP(ctx, hipFuncSetAttribute((const void*)k_sgbm_band<NP, true, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                VO_HIP(ctx, hipFuncSetAttribute((const void*)k_sgbm_band<NP, false, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_done |= 1ull << (ctx->device & 63);
-            }
-            {
-                StageTimer t(ctx, VO_T_SGBM_AGG);
-                const int nw = div_up(g.H, 4);
-                if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 3 * vol, g, ctx->dump);
-                else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 3 * vol, g, ctx->dump);
-                PathPlan pd = plan_all;
-                const int src[3] = { 4, 2, 3 };                       // N, NW, NE: the order k_sgbm_band indexes the checkpoints by
-                pd.n_dirs = 3;
-                pd.first_wave[0] = 0;
-                for (int k = 0; k < 3; k++) {
-                    pd.sx[k] = plan_all.sx[src[k]]; pd.sy[k] = plan_all.sy[src[k]]; pd.nlines[k] = plan_all.nlines[src[k]];
-                    pd.first_wave[k + 1] = pd.first_wave[k] + div_up(pd.nlines[k], 4);
-                }
-                for (int k = 3; k < VO_MAX_DIRS; k++) { pd.sx[k] = pd.sy[k] = pd.nlines[k] = 0; pd.first_wave[k + 1] = pd.first_wave[3]; }
-                const int nwaves = pd.first_wave[3];
-                if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, 8, 16, true, 2>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, (size_t)nb, g, pd, ctx->dump);
-                else hipLaunchKernelGGL((k_sgbm_paths<NP, 8, 16, false, 2>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, (size_t)nb, g, pd, ctx->dump);
-                VO_CHECK_LAUNCH(ctx);
-            }
-            {
-                StageTimer t(ctx, VO_T_SGBM_WTA);
-                if (pad) hipLaunchKernelGGL((k_sgbm_band<NP, true, TW>), dim3(div_up(g.W1, TW), nb), dim3(256), lds, ctx->stream, ctx->C, ctx->S, ctx->S + vol, nb, g, ctx->disp_tmp, ctx->ccl_size);
-                else hipLaunchKernelGGL((k_sgbm_band<NP, false, TW>), dim3(div_up(g.W1, TW), nb), dim3(256), lds, ctx->stream, ctx->C, ctx->S, ctx->S + vol, nb, g, ctx->disp_tmp, ctx->ccl_size);
-                VO_CHECK_LAUNCH(ctx);
-            }
-            ctx->last_paths = 4;
-            return VO_OK;
-        }
-    }
-    // MODE_HH with the pair schedule: all three opposite pairs that do not involve the final sweep's own direction
-    // (W/E, NW/SE, NE/SW) as one stored volume each (k_sgbm_pair), the bottom-up vertical direction by the line kernel,
-    // the fused sweep over four volumes.  Layout of S: [0..2] = the pair sums, [3] = S direction, [4..6] = checkpoints.
-    if constexpr (NP % 2 == 0 && NP <= 8) {
-        if (fuse && ctx->we_now && ctx->tune_pair_hh && ctx->tune_vwta32 && plan.lpw == 4 && plan_all.n_dirs == 8) {
-            const bool pad = g.D != g.Dp;
-            {
-                StageTimer t(ctx, VO_T_SGBM_AGG);
-                PathPlan pp = plan_all;
-                const int src[3] = { 0, 2, 3 };                       // (1,0), (1,1), (-1,1): the forward member of each pair
-                pp.n_dirs = 3;
-                pp.first_wave[0] = 0;
-                for (int k = 0; k < 3; k++) {
-                    pp.sx[k] = plan_all.sx[src[k]]; pp.sy[k] = plan_all.sy[src[k]]; pp.nlines[k] = plan_all.nlines[src[k]];
-                    pp.first_wave[k + 1] = pp.first_wave[k] + div_up(pp.nlines[k], 4);
-                }
-                for (int k = 3; k < VO_MAX_DIRS; k++) { pp.sx[k] = pp.sy[k] = pp.nlines[k] = 0; pp.first_wave[k + 1] = pp.first_wave[3]; }
-                const int nwp = pp.first_wave[3];
-                if (pad) hipLaunchKernelGGL((k_sgbm_pair<NP, true>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 4 * vol, vol, g, pp, ctx->dump);
-                else hipLaunchKernelGGL((k_sgbm_pair<NP, false>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ctx->S + 4 * vol, vol, g, pp, ctx->dump);
-                PathPlan pd = plan_all;
-                pd.n_dirs = 1;
-                pd.sx[0] = plan_all.sx[6]; pd.sy[0] = plan_all.sy[6]; pd.nlines[0] = plan_all.nlines[6];
-                pd.first_wave[0] = 0;
-                for (int k = 0; k < VO_MAX_DIRS; k++) pd.first_wave[k + 1] = div_up(pd.nlines[0], 4);
-                for (int k = 1; k < VO_MAX_DIRS; k++) pd.sx[k] = pd.sy[k] = pd.nlines[k] = 0;
-                const int nwaves = pd.first_wave[1];
-                constexpr int PFD = NP <= 4 ? 8 : 4;
-                if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, true, 1>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + 3 * vol, vol, g, pd, ctx->dump);
-                else hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, false, 1>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + 3 * vol, vol, g, pd, ctx->dump);
-                VO_CHECK_LAUNCH(ctx);
-            }
-            {
-                StageTimer t(ctx, VO_T_SGBM_WTA);
-                constexpr int NP2 = NP / 2;
-                const int nw2 = div_up(g.W1, 2);
-                const size_t sh32 = (size_t)8 * 2 * g.Dp * sizeof(int16_t);
-                if (ctx->tune_vwta_queued == 16 && ctx->tune_we_fuse == 2 && NP <= 4) {   // (8 registers per lane and volume: the 32-lane form wins, measured on config 4)
-                    const int nw16 = div_up(g.W1, 4);
-                    const size_t sh16 = (size_t)2 * 16 * g.Dp * sizeof(int16_t);
-                    if (pad) hipLaunchKernelGGL((k_sgbm_vwta<NP, 4, true>), dim3(div_up(nw16, 4)), dim3(256), sh16, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
-                    else hipLaunchKernelGGL((k_sgbm_vwta<NP, 4, false>), dim3(div_up(nw16, 4)), dim3(256), sh16, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
-                } else if (pad) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 4, true>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
-                else hipLaunchKernelGGL((k_sgbm_vwta32<NP2, 4, false>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
-                hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
-                VO_CHECK_LAUNCH(ctx);
-            }
-            ctx->last_paths = plan_all.n_dirs - 1;
-            return VO_OK;
-        }
-    }
-    if constexpr (NP % 2 == 0 && NP <= 8) {
-        if (fuse && ctx->we_now && ctx->tune_vwta32 && plan.lpw == 4 && g.W1 % 8 == 0 && g.W1 >= 16) {
-            const bool pad = g.D != g.Dp;
-            const int ND = plan_all.n_dirs - 3;               // stored directions besides W and E: 2 (MODE_SGBM) or 5 (MODE_HH)
-            {
-                StageTimer t(ctx, VO_T_SGBM_AGG);
-                const int nw = div_up(g.H, 4);
-                int16_t* ck = ctx->S + (size_t)(ND + 1) * vol;
-                if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ck, g, ctx->dump);
-                else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, ck, g, ctx->dump);
-                PathPlan pd = plan_all;
-                pd.n_dirs = ND;
-                pd.first_wave[0] = 0;
-                for (int k = 0; k < ND; k++) {
-                    pd.sx[k] = plan_all.sx[2 + k]; pd.sy[k] = plan_all.sy[2 + k]; pd.nlines[k] = plan_all.nlines[2 + k];
-                    pd.first_wave[k + 1] = pd.first_wave[k] + div_up(pd.nlines[k], 4);
-                }
-                for (int k = ND; k < VO_MAX_DIRS; k++) { pd.sx[k] = pd.sy[k] = pd.nlines[k] = 0; pd.first_wave[k + 1] = pd.first_wave[ND]; }
-                const int nwaves = pd.first_wave[ND];
-                constexpr int PFD = NP <= 4 ? 8 : 4;
-                if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, true, 1>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, vol, g, pd, ctx->dump);
-                else hipLaunchKernelGGL((k_sgbm_paths<NP, PFD, 16, false, 1>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S + vol, vol, g, pd, ctx->dump);
-                VO_CHECK_LAUNCH(ctx);
-            }
-            {
-                StageTimer t(ctx, VO_T_SGBM_WTA);
-                constexpr int NP2 = NP / 2;
-                const int nw2 = div_up(g.W1, 2);
-                const size_t sh32 = (size_t)8 * 2 * g.Dp * sizeof(int16_t);
-#define LAUNCH_VWTA32_WE(NV, PAD) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, NV, PAD>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen)
-                bool done64 = false;
-                if constexpr (NP % 4 == 0) {
-                    if (ctx->tune_vwta64 && !pad && ND == 2) {
-                        hipLaunchKernelGGL((k_sgbm_vwta64<NP / 4, 3>), dim3(div_up(g.W1, 4)), dim3(256), (size_t)4 * 2 * g.Dp * sizeof(int16_t), ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
-                        done64 = true;
-                    }
-                }
-                // a pair on this schedule is not waited for soon: the 16-lane form of the sweep (half the waves, a third
-                // fewer instructions per pixel) serves throughput, the 32-lane form latency (VO_VWTA_QUEUED=32 to force it)
-                const int nw16 = div_up(g.W1, 4);
-                const size_t sh16 = (size_t)2 * 16 * g.Dp * sizeof(int16_t);
-#define LAUNCH_VWTA16_WE(NV, PAD) hipLaunchKernelGGL((k_sgbm_vwta<NP, NV, PAD>), dim3(div_up(nw16, 4)), dim3(256), sh16, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen)
-                if (done64) {
-                } else if (ctx->tune_vwta_queued == 16 && ctx->tune_we_fuse == 2 && NP <= 4) {
-                    if (ND == 2) { if (pad) LAUNCH_VWTA16_WE(3, true); else LAUNCH_VWTA16_WE(3, false); }
-                    else { if (pad) LAUNCH_VWTA16_WE(6, true); else LAUNCH_VWTA16_WE(6, false); }
-                    done64 = true;
-                }
-#undef LAUNCH_VWTA16_WE
-                if (done64) {
-                } else if (ND == 2) { if (pad) LAUNCH_VWTA32_WE(3, true); else LAUNCH_VWTA32_WE(3, false); }
-                else { if (pad) LAUNCH_VWTA32_WE(6, true); else LAUNCH_VWTA32_WE(6, false); }
-#undef LAUNCH_VWTA32_WE
-                hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
-                VO_CHECK_LAUNCH(ctx);
-            }
-            ctx->last_paths = plan_all.n_dirs - 1;
-            return VO_OK;
-        }
-    }
+    if ((rc = ensure_S(ctx, plan.n_dirs))) return rc;
     {
         StageTimer t(ctx, VO_T_SGBM_AGG);
         const int nwaves = plan.first_wave[plan.n_dirs];
-        const bool pad = g.D != g.Dp;
-#define LAUNCH_PATHS(NPL, PF, LPL, PAD) hipLaunchKernelGGL((k_sgbm_paths<NPL, PF, LPL, PAD>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump)
-        bool done = false;
-        if constexpr (NP <= 4) {
-            if (plan.lpw == 8) {
-                done = true;
-                if (ctx->tune_path_pf == 8) { if (pad) LAUNCH_PATHS(2 * NP, 8, 8, true); else LAUNCH_PATHS(2 * NP, 8, 8, false); }
-                else { if (pad) LAUNCH_PATHS(2 * NP, 4, 8, true); else LAUNCH_PATHS(2 * NP, 4, 8, false); }
-            }
-        }
-        if (done) {
-        } else if (ctx->tune_path_pf == 8 && NP <= 4) { if (pad) LAUNCH_PATHS(NP, 8, 16, true); else LAUNCH_PATHS(NP, 8, 16, false); }
-        else if (ctx->tune_path_pf == 2) { if (pad) LAUNCH_PATHS(NP, 2, 16, true); else LAUNCH_PATHS(NP, 2, 16, false); }
-        else { if (pad) LAUNCH_PATHS(NP, 4, 16, true); else LAUNCH_PATHS(NP, 4, 16, false); }
-#undef LAUNCH_PATHS
+        constexpr int PF = NP <= 4 ? 8 : 4;
+        if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, PF, true>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump);
+        else hipLaunchKernelGGL((k_sgbm_paths<NP, PF, false>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump);
         VO_CHECK_LAUNCH(ctx);
     }
     {
         StageTimer t(ctx, VO_T_SGBM_WTA);
-        const size_t sh = (size_t)16 * g.Dp * sizeof(int16_t);   // one row of S per 16-lane group (the fused sweep keeps two)
-        if (fuse) {
-            if (ctx->tune_vwta32 && NP % 2 == 0) {
-                // 32 lanes per column: Dp / 64 registers per lane, two columns per wave
-                constexpr int NP2 = NP % 2 == 0 ? NP / 2 : 1;
-                const int nw2 = div_up(g.W1, 2);
-                const size_t sh32 = (size_t)8 * 2 * g.Dp * sizeof(int16_t);   // 8 column groups per 256-thread block, two rows of S each
-#define LAUNCH_VWTA32(NV, PAD) hipLaunchKernelGGL((k_sgbm_vwta32<NP2, NV, PAD>), dim3(div_up(nw2, 4)), dim3(256), sh32, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen)
-                bool done64 = false;
-                if constexpr (NP % 4 == 0) {
-                    if (ctx->tune_vwta64 && g.D == g.Dp && plan.n_dirs == 4) {
-                        hipLaunchKernelGGL((k_sgbm_vwta64<NP / 4, 4>), dim3(div_up(g.W1, 4)), dim3(256), (size_t)4 * 2 * g.Dp * sizeof(int16_t), ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen);
-                        done64 = true;
-                    }
-                }
-                if (done64) {
-                } else if (plan.n_dirs == 4) { if (g.D == g.Dp) LAUNCH_VWTA32(4, false); else LAUNCH_VWTA32(4, true); }
-                else { if (g.D == g.Dp) LAUNCH_VWTA32(7, false); else LAUNCH_VWTA32(7, true); }
-#undef LAUNCH_VWTA32
-                hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
-                VO_CHECK_LAUNCH(ctx);
-                return VO_OK;
-            }
-            const int nw = div_up(g.W1, 4);
-            // the sweep leaves a two-word record per pixel in ccl_label / ccl_runlen (free until the speckle
-            // filter); k_sgbm_fin turns the records into disp1 + the disp2 atomicMin for all pixels in parallel
-            // (an atomic or an LDS round trip inside the sequential sweep costs it a third of its time)
-#define LAUNCH_VWTA(NV, PAD) hipLaunchKernelGGL((k_sgbm_vwta<NP, NV, PAD>), dim3(div_up(nw, 4)), dim3(256), 2 * sh, ctx->stream, ctx->C, ctx->S, vol, g, ctx->ccl_label, ctx->ccl_runlen)
-            if (plan.n_dirs == 4) { if (g.D == g.Dp) LAUNCH_VWTA(4, false); else LAUNCH_VWTA(4, true); }
-            else { if (g.D == g.Dp) LAUNCH_VWTA(7, false); else LAUNCH_VWTA(7, true); }
-#undef LAUNCH_VWTA
-            hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
-        } else {
-            const long long npix = (long long)g.W1 * g.H;
-            hipLaunchKernelGGL((k_sgbm_wta<NP>), dim3((unsigned)((npix + 15) / 16)), dim3(256), sh, ctx->stream, ctx->S, vol, plan.n_dirs,
-                               g, ctx->disp_tmp, ctx->ccl_size);
-        }
+        const size_t sh = (size_t)16 * g.Dp * sizeof(int16_t);   // one row of S per 16-lane group
+        const long long npix = (long long)g.W1 * g.H;
+        hipLaunchKernelGGL((k_sgbm_wta<NP>), dim3((unsigned)((npix + 15) / 16)), dim3(256), sh, ctx->stream, ctx->S, vol, plan.n_dirs,
+                           g, ctx->disp_tmp, ctx->ccl_size);
         VO_CHECK_LAUNCH(ctx);
     }
+    ctx->last_paths = plan.n_dirs;
+    ctx->last_schedule = VO_SCHED_UNFUSED;
     return VO_OK;
 }
 
 static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);
 
-// The SGBM workspaces (planes, C, L volumes, CCL arrays) are shared by the main and the look-ahead
+// The SGBM workspaces (planes, C, S volumes, CCL arrays) are shared by the main and the look-ahead
 // stream: a run on one stream must not start before the previous run -- possibly on the other
 // stream -- has finished.  An event chain orders them on the device without blocking the host.
 int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp)
@@ -2063,6 +1250,11 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
     SgbmGeom g;
     g.W = w; g.H = h; g.D = e.D; g.Dp = (e.D + 31) & ~31; g.minD = e.minD; g.P1 = e.P1; g.P2 = e.P2; g.ur = e.ur; g.d12 = e.d12;
     g.ftzero = e.ftzero; g.SW2 = e.SW2;
+    {
+        const int u = 100 - e.ur;                // (only used when 1 <= u <= 100: the threshold form of the uniqueness test)
+        g.urM = u > 1 ? (uint32_t)((0x100000000ull + (uint64_t)u - 1) / (uint64_t)u) : 0xFFFFFFFFu;
+        g.urAdd = u > 1 ? (uint32_t)(u - 1) : 1u;
+    }
     g.minX1 = e.maxD > 0 ? e.maxD : 0;
     int maxX1 = w + (e.minD < 0 ? e.minD : 0);
     g.W1 = maxX1 - g.minX1;
@@ -2078,16 +1270,13 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
     const size_t vol = (size_t)g.W1 * h * g.Dp;
     if (vol > ctx->vol_cells || e.D > 256)
         return vo_fail(ctx, VO_E_CAP, "cost volume %zu cells exceeds the capacity given to vo_create (or D > 256)", vol);
-    // 8 lanes per scan line (16 disparities per lane) up to D = 128 in the line scheme; 16 lanes per line otherwise
-    const bool lanes8 = ctx->tune_path_lanes == 8 && g.Dp <= 128 && !(ctx->tune_raster && ctx->tune_fuse_wta && g.ur < 100);
-    const PathPlan plan = make_plan(g, e.mode, lanes8 ? 8 : 4);
+    const PathPlan plan = make_plan(g, e.mode);
     ctx->last_cells = (int64_t)g.W1 * h * g.D;
-    ctx->last_paths = (ctx->tune_fuse_wta && g.ur < 100) ? plan.n_dirs - 1 : plan.n_dirs;   // directions inside the k_sgbm_paths launch
     {
         StageTimer t(ctx, VO_T_SGBM_COST);
         const int dbg = ctx->tune_diag_dbg;          // development only (VO_DIAG_DEBUG): 4 / 8 / 16 / 32 skip the cost / W+E / diagonal / post stage
         hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
-                           ctx->planesL, ctx->planesR, ctx->ccl_size, ctx->rs_ctl, ctx->rs_ctl_words);
+                           ctx->planesL, ctx->planesR, ctx->ccl_size, ctx->sw_ctl, ctx->sw_ctl_words);
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
         const int TY = ctx->tune_sweep_ty;
         const int nw = bx / 64;
@@ -2099,7 +1288,7 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
         switch (g.SW2) {
             case 0: LAUNCH_SWEEP(8, 0); break;
             case 1: LAUNCH_SWEEP(8, 1); break;
-            case 2: if (ctx->tune_sweep_xt == 16) LAUNCH_SWEEP(16, 2); else LAUNCH_SWEEP(8, 2); break;
+            case 2: LAUNCH_SWEEP(8, 2); break;
             case 3: LAUNCH_SWEEP(8, 3); break;
             case 4: LAUNCH_SWEEP(8, 4); break;
             case 5: LAUNCH_SWEEP(8, 5); break;
@@ -2121,15 +1310,6 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
         default: rc = launch_agg<8>(ctx, g, plan, vol); break;
     }
     if (rc) return rc;
-    if (ctx->stream_hi && !ctx->on_hi && ctx->cur_engine >= 0) {
-        // the rest of this pair (post filters, then the ORB chain) is a chain of short latency-bound launches: it
-        // continues on the engine's high-priority stream, behind everything queued so far
-        hipEvent_t hop = ctx->la_hop[ctx->cur_engine];
-        VO_HIP(ctx, hipEventRecord(hop, ctx->stream));
-        VO_HIP(ctx, hipStreamWaitEvent(ctx->stream_hi, hop, 0));
-        std::swap(ctx->stream, ctx->stream_hi);
-        ctx->on_hi = true;
-    }
     if (!(ctx->tune_diag_dbg & 32)) {
         StageTimer t(ctx, VO_T_SGBM_POST);
         hipLaunchKernelGGL(k_lr_median3, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, ctx->disp_tmp, ctx->ccl_size, g, d_disp);

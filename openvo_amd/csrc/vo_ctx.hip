@@ -155,15 +155,12 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->planesL, npx * 2); DALLOC(ctx->planesR, npx * 6);
     ctx->vol_cells = npx * (size_t)((max_disp + 31) & ~31);
     DALLOC(ctx->C, ctx->vol_cells);
-    if (const char* e9 = getenv("VO_RASTER")) ctx->tune_raster = atoi(e9) ? 1 : 0;
-    // raster scheme: one extra volume (the E direction, or the reverse pass's sum); the line-per-direction
-    // scheme stores one volume per direction (grown on demand)
-    ctx->S_vols = (ctx->tune_raster && getenv("VO_RASTER_AFTER") == nullptr) ? 1 : 5;
+    // aggregated volumes: L_W + L_E, MODE_HH's reverse-pass sum, checkpoints (grown on demand for uniquenessRatio >= 100)
+    ctx->S_vols = 3;
     DALLOC(ctx->S, ctx->vol_cells * ctx->S_vols);
-    DALLOC(ctx->rs_bnd, ctx->vol_cells / 4 + 4096);      // uint64 words: one volume's worth of bytes
-    ctx->rs_ctl_words = 2 * 2048;                        // two control blocks: {ticket, error, ...} + per-strip timeline of the diagonal sweep
-    DALLOC(ctx->rs_ctl, ctx->rs_ctl_words);
-    VO_HIP(ctx, hipMemset(ctx->rs_ctl, 0, ctx->rs_ctl_words * sizeof(int)));
+    ctx->sw_ctl_words = 2 * 2048;                        // two control blocks: {work items taken, sticky error, ...} + per-strip timeline
+    DALLOC(ctx->sw_ctl, ctx->sw_ctl_words);
+    VO_HIP(ctx, hipMemset(ctx->sw_ctl, 0, ctx->sw_ctl_words * sizeof(int)));
     DALLOC(ctx->disp_tmp, npx); DALLOC(ctx->dump, 4096);
     DALLOC(ctx->ccl_label, npx); DALLOC(ctx->ccl_size, npx); DALLOC(ctx->ccl_runlen, npx);
     // ORB: 8-level pyramid is < 3.2x the base image
@@ -193,34 +190,24 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
         g_create_err = "hipHostMalloc failed"; vo_destroy(ctx); return VO_E_HIP;
     }
     for (int s = 0; s <= VO_NUM_SLOTS; s++) ctx->slots[s].n_kp_host = ctx->slot_words + s;
-    if (const char* e3 = getenv("VO_PATH_PF")) { int v = atoi(e3); if (v == 2 || v == 4 || v == 8) ctx->tune_path_pf = v; }
     if (const char* e8 = getenv("VO_ENGINES")) { int v = atoi(e8); if (v >= 1 && v <= vo_ctx::MAX_ENGINES) ctx->n_engines = v; }
     {
-        // every engine owns a full SGBM workspace (cost volume + up to 8 path volumes): keep all of them within ~96 GB
-        const double per_engine = (double)ctx->vol_cells * 2.0 * 9.5;
-        const int fit = (int)(96e9 / per_engine);
+        // every engine owns a full SGBM workspace: cost volume + 3 aggregated volumes + boundary granules (< 1 volume) + planes.
+        // Keep all of them within 40 % of what the device has free right now (frame slots, ORB scratch and the caller's staged
+        // inputs need room too).
+        const double per_engine = (double)ctx->vol_cells * 2.0 * 5.0 + (double)npx * 64.0;
+        size_t free_b = 0, total_b = 0;
+        double budget = 96e9;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = 0.4 * (double)free_b;
+        const int fit = (int)(budget / per_engine);
         if (ctx->n_engines > fit) ctx->n_engines = fit < 2 ? 2 : fit;
     }
-    if (const char* e7 = getenv("VO_FUSE_WTA")) ctx->tune_fuse_wta = atoi(e7) ? 1 : 0;
-    if (const char* e14 = getenv("VO_VWTA32")) ctx->tune_vwta32 = atoi(e14) ? 1 : 0;
-    if (const char* e15 = getenv("VO_PATH_LANES")) ctx->tune_path_lanes = atoi(e15) == 8 ? 8 : 16;
-    if (const char* e16 = getenv("VO_WE_FUSE")) { int v = atoi(e16); ctx->tune_we_fuse = v == 2 ? 2 : (v ? 1 : 0); }
-    if (const char* e19 = getenv("VO_PAIR_HH")) ctx->tune_pair_hh = atoi(e19) ? 1 : 0;
-    if (const char* e22 = getenv("VO_VWTA64")) ctx->tune_vwta64 = atoi(e22) ? 1 : 0;
-    if (const char* e23 = getenv("VO_VWTA_QUEUED")) ctx->tune_vwta_queued = atoi(e23) == 32 ? 32 : 16;
-    if (const char* e24 = getenv("VO_DIAG")) ctx->tune_diag = atoi(e24) ? 1 : 0;
+    if (const char* e27 = getenv("VO_DIAG_WGS")) ctx->tune_diag_wgs = atoi(e27);
     if (const char* e26 = getenv("VO_DIAG_DEBUG")) ctx->tune_diag_dbg = atoi(e26);
-    if (const char* e25 = getenv("VO_DIAG_WAVES")) ctx->tune_diag_nwc = atoi(e25) == 7 ? 7 : 15;
-    if (const char* e20 = getenv("VO_BAND")) { int v = atoi(e20); ctx->tune_band = v == 2 ? 2 : (v ? 1 : 0); }
-    ctx->band_now = ctx->tune_band == 1;
-    if (const char* e17 = getenv("VO_WE_AFTER")) ctx->we_after = atoi(e17);
-    if (const char* e18 = getenv("VO_WE_TAIL")) ctx->we_tail = atoi(e18);
-    ctx->we_now = ctx->tune_we_fuse == 1;
-    if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);
-    if (const char* e11 = getenv("VO_PRIO")) ctx->tune_prio = atoi(e11);
-    if (const char* e12 = getenv("VO_RASTER_AFTER")) ctx->raster_after = atoi(e12);
-    if (const char* e13 = getenv("VO_RASTER_WGS")) { int v = atoi(e13); if (v >= 1 && v <= 4096) ctx->tune_raster_wgs = v; }
-    if (const char* e5 = getenv("VO_SWEEP_XT")) { int v = atoi(e5); if (v == 8 || v == 16) ctx->tune_sweep_xt = v; }
+    if (const char* e25 = getenv("VO_DIAG_WAVES")) ctx->tune_diag_nwc = atoi(e25) == 15 ? 15 : 7;
+#ifdef VO_TEST_HOOKS
+    if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);   // test-only build (libvo355_hooks.so)
+#endif
     if (const char* e6 = getenv("VO_SWEEP_TY")) { int v = atoi(e6); if (v >= 4 && v <= 4096) ctx->tune_sweep_ty = v; }
     *out = ctx;
     return VO_OK;
@@ -239,7 +226,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         if (f.ready) (void)hipEventDestroy(f.ready);
     }
     void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
-                   ctx->C, ctx->S, ctx->rs_bnd, ctx->rs_ctl, ctx->disp_tmp, ctx->dump, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
+                   ctx->C, ctx->S, ctx->sw_bnd, ctx->sw_ctl, ctx->disp_tmp, ctx->dump, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
                    ctx->m_idx, ctx->m_dist, ctx->pts_a, ctx->pts_b, ctx->st_a, ctx->st_b, ctx->xy_a, ctx->xy_b,
                    ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws, ctx->ransac_ws };
     for (void* p : ps) if (p) (void)hipFree(p);
@@ -252,15 +239,13 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     if (ctx->sgbm_done) (void)hipEventDestroy(ctx->sgbm_done);
     for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) {
         vo_ctx::SgbmWs& a = ctx->ws_alt[k];
-        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.rs_bnd, a.rs_ctl, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->la_stage[k] };
+        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.sw_bnd, a.sw_ctl, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->la_stage[k] };
         for (void* q : pa) if (q) (void)hipFree(q);
         if (a.done) (void)hipEventDestroy(a.done);
         orb_ws_free(a.orb);
         if (a.pinned) (void)hipHostFree(a.pinned);
         if (a.h2d_done) (void)hipEventDestroy(a.h2d_done);
         if (ctx->la_stream[k]) (void)hipStreamDestroy(ctx->la_stream[k]);
-        if (ctx->la_stream_hi[k]) { (void)hipStreamSynchronize(ctx->la_stream_hi[k]); (void)hipStreamDestroy(ctx->la_stream_hi[k]); }
-        if (ctx->la_hop[k]) (void)hipEventDestroy(ctx->la_hop[k]);
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -278,10 +263,8 @@ extern "C" int vo_device_name(const vo_ctx* ctx, char* buf, int buflen)
 extern "C" int vo_synchronize(vo_ctx* ctx)
 {
     if (!ctx) return VO_E_ARG;
-    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) {
+    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++)
         if (ctx->la_stream[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream[k]));
-        if (ctx->la_stream_hi[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream_hi[k]));
-    }
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }
@@ -412,7 +395,7 @@ extern "C" int vo_upload_pair(vo_ctx* ctx, int slot, const uint8_t* left, const 
     if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context %dx%d", w, h, ctx->max_w, ctx->max_h);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     FrameSlot& f = ctx->slots[slot];
-    if ((rc = slot_wait(ctx, f))) return rc;
+    if ((rc = slot_wait(ctx, f)) || (rc = slot_before_overwrite(ctx, f))) return rc;
     StageTimer t(ctx, VO_T_UPLOAD);
     // the two cameras use disjoint halves of the staging buffer (4 bytes/pixel each would be
     // needed for colour + gray; stage_in holds 6 bytes/pixel)
@@ -434,7 +417,7 @@ extern "C" int vo_upload_mono(vo_ctx* ctx, int slot, const uint8_t* img, int w, 
     if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context %dx%d", w, h, ctx->max_w, ctx->max_h);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     FrameSlot& f = ctx->slots[slot];
-    if ((rc = slot_wait(ctx, f))) return rc;
+    if ((rc = slot_wait(ctx, f)) || (rc = slot_before_overwrite(ctx, f))) return rc;
     StageTimer t(ctx, VO_T_UPLOAD);
     if ((rc = ingest(ctx, 0, img, w, h, channels, 1, f.left, ctx->stage_in))) return rc;
     f.w = w; f.h = h; f.has_pair = true; f.has_disp = false; f.has_kp = false; f.n_kp = 0; f.kp_pending = false;
@@ -476,7 +459,7 @@ extern "C" int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preproc
     const int w = ctx->staged_w, h = ctx->staged_h;
     const size_t per = (size_t)w * h * ctx->staged_ch;
     StageTimer t(ctx, VO_T_UPLOAD);
-    if ((rc = slot_wait(ctx, f))) return rc;
+    if ((rc = slot_wait(ctx, f)) || (rc = slot_before_overwrite(ctx, f))) return rc;
     rc = ingest(ctx, 0, ctx->staged + per * 2 * index, w, h, ctx->staged_ch, preprocessed, f.left, ctx->stage_in, hipMemcpyDeviceToDevice);
     if (rc) return rc;
     rc = ingest(ctx, 1, ctx->staged + per * (2 * index + 1), w, h, ctx->staged_ch, preprocessed, f.right, ctx->stage_in, hipMemcpyDeviceToDevice);
@@ -490,14 +473,13 @@ extern "C" int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preproc
 static void engine_swap(vo_ctx* ctx, int engine)
 {
     std::swap(ctx->stream, ctx->la_stream[engine]);
-    std::swap(ctx->stream_hi, ctx->la_stream_hi[engine]);
     std::swap(ctx->stage_in, ctx->la_stage[engine]);
     vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
     std::swap(ctx->orb, a.orb);   // every engine has its own ORB scratch
     if (engine == 0) return;
     std::swap(ctx->planesL, a.planesL); std::swap(ctx->planesR, a.planesR);
     std::swap(ctx->C, a.C); std::swap(ctx->S, a.S); std::swap(ctx->S_vols, a.S_vols);
-    std::swap(ctx->rs_bnd, a.rs_bnd); std::swap(ctx->rs_ctl, a.rs_ctl); std::swap(ctx->sw_tag, a.sw_tag);
+    std::swap(ctx->sw_bnd, a.sw_bnd); std::swap(ctx->sw_bnd_bytes, a.sw_bnd_bytes); std::swap(ctx->sw_ctl, a.sw_ctl); std::swap(ctx->sw_tag, a.sw_tag);
     std::swap(ctx->disp_tmp, a.disp_tmp);
     std::swap(ctx->ccl_runlen, a.ccl_runlen); std::swap(ctx->ccl_label, a.ccl_label); std::swap(ctx->ccl_size, a.ccl_size);
     std::swap(ctx->sgbm_done, a.done); std::swap(ctx->sgbm_done_valid, a.done_valid);
@@ -512,7 +494,6 @@ struct EngineScope {
     EngineScope(vo_ctx* c, int e) : ctx(c), engine(e) { engine_swap(ctx, engine); ctx->cur_engine = engine; }
     ~EngineScope()
     {
-        if (ctx->on_hi) { std::swap(ctx->stream, ctx->stream_hi); ctx->on_hi = false; }   // back from the tail's stream
         ctx->cur_engine = -1;
         engine_swap(ctx, engine);
     }
@@ -523,34 +504,28 @@ struct EngineScope {
 static int engine_prepare(vo_ctx* ctx, int engine)
 {
     if (!ctx->la_stream[engine]) {
-        if (ctx->tune_prio) {
-            int lo = 0, hi = 0;    // numerically lower = higher priority
-            VO_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-            VO_HIP(ctx, hipStreamCreateWithPriority(&ctx->la_stream[engine], hipStreamNonBlocking, lo));
-            VO_HIP(ctx, hipStreamCreateWithPriority(&ctx->la_stream_hi[engine], hipStreamNonBlocking, hi));
-            VO_HIP(ctx, hipEventCreateWithFlags(&ctx->la_hop[engine], hipEventDisableTiming));
-        } else
-            VO_HIP(ctx, hipStreamCreateWithFlags(&ctx->la_stream[engine], hipStreamNonBlocking));
+        VO_HIP(ctx, hipStreamCreateWithFlags(&ctx->la_stream[engine], hipStreamNonBlocking));
         VO_HIP(ctx, hipMalloc((void**)&ctx->la_stage[engine], ctx->stage_bytes * 2 + 256));
         if (orb_ws_alloc(ctx, ctx->ws_alt[engine].orb)) return vo_fail(ctx, VO_E_HIP, "hipMalloc failed (look-ahead ORB workspace)");
     }
     if (engine == 0 || ctx->ws_alt[engine].ready) return VO_OK;
     vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
     const size_t npx = (size_t)ctx->max_w * ctx->max_h;
-    const int vols = ctx->S_vols;
-    VO_HIP(ctx, hipMalloc((void**)&a.planesL, npx * 2 * 4 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&a.planesR, npx * 6 * 4 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&a.C, ctx->vol_cells * 2 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&a.S, ctx->vol_cells * 2 * vols + 256));
+    const int vols = 3;                          // L_W + L_E, MODE_HH's reverse-pass sum, checkpoints (ensure_S grows it if ever needed)
+    void** ps[] = { (void**)&a.planesL, (void**)&a.planesR, (void**)&a.C, (void**)&a.S, (void**)&a.sw_ctl, (void**)&a.disp_tmp,
+                    (void**)&a.ccl_runlen, (void**)&a.ccl_label, (void**)&a.ccl_size };
+    const size_t sz[] = { npx * 2 * 4, npx * 6 * 4, ctx->vol_cells * 2, ctx->vol_cells * 2 * vols, ctx->sw_ctl_words * sizeof(int), npx * 2,
+                          npx * 4, npx * 4, npx * 4 };
+    hipError_t e = hipSuccess;
+    for (size_t k = 0; k < sizeof(ps) / sizeof(ps[0]) && e == hipSuccess; k++) e = hipMalloc(ps[k], sz[k] + 256);
+    if (e == hipSuccess) e = hipMemset(a.sw_ctl, 0, ctx->sw_ctl_words * sizeof(int));
+    if (e == hipSuccess && !a.done) e = hipEventCreateWithFlags(&a.done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        // a partly built workspace is given back whole: the next call starts from nothing instead of leaking these
+        for (void** q : ps) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        return vo_fail(ctx, VO_E_HIP, "look-ahead engine %d: workspace allocation failed: %s", engine, hipGetErrorString(e));
+    }
     a.S_vols = vols;
-    VO_HIP(ctx, hipMalloc((void**)&a.rs_bnd, (ctx->vol_cells / 4 + 4096) * 8 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&a.rs_ctl, ctx->rs_ctl_words * sizeof(int) + 256));
-    VO_HIP(ctx, hipMemset(a.rs_ctl, 0, ctx->rs_ctl_words * sizeof(int)));
-    VO_HIP(ctx, hipMalloc((void**)&a.disp_tmp, npx * 2 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&a.ccl_runlen, npx * 4 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&a.ccl_label, npx * 4 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&a.ccl_size, npx * 4 + 256));
-    VO_HIP(ctx, hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
     a.ready = true;
     return VO_OK;
 }
@@ -560,8 +535,30 @@ int slot_wait(vo_ctx* ctx, FrameSlot& f)
     if (f.pending) {
         VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, f.ready, 0));
         f.pending = false;
-        if (ctx->inflight > 0) ctx->inflight--;
+        if (f.counted && ctx->inflight > 0) ctx->inflight--;
+        f.counted = false;
     }
+    return VO_OK;
+}
+
+// the caller gives up a look-ahead slot without consuming it (a prediction that did not come true): its work may still be
+// running -- the slot stays `pending` for ordering -- but it no longer counts as in flight
+extern "C" int vo_lookahead_drop(vo_ctx* ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= VO_NUM_SLOTS) return vo_fail(ctx, VO_E_ARG, "vo_lookahead_drop: bad slot");
+    FrameSlot& f = ctx->slots[slot];
+    if (f.pending && f.counted && ctx->inflight > 0) ctx->inflight--;
+    f.counted = false;
+    return VO_OK;
+}
+
+int slot_before_overwrite(vo_ctx* ctx, FrameSlot& f)
+{
+    // an earlier look-ahead run into this slot that nobody waited for (a voided prediction) may still be writing it on
+    // another engine's stream, and pose steps started ahead may still be reading it on theirs
+    if (f.pending) VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, f.ready, 0));
+    for (hipEvent_t& r : f.readers)
+        if (r) { VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, r, 0)); r = nullptr; }
     return VO_OK;
 }
 
@@ -594,7 +591,8 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
     f.w = w; f.h = h; f.has_kp = false; f.n_kp = 0; f.kp_pending = false;
     {
         EngineScope on_engine(ctx, engine);          // ctx->stream / staging / SGBM + ORB workspaces are the engine's in here
-        {
+        rc = slot_before_overwrite(ctx, f);
+        if (!rc) {
             StageTimer t(ctx, VO_T_UPLOAD);
             rc = ingest(ctx, 0, srcL, w, h, channels, preprocessed, f.left, ctx->stage_in, kind);
             if (!rc) rc = ingest(ctx, 1, srcR, w, h, channels, preprocessed, f.right, ctx->stage_in, kind);
@@ -604,24 +602,11 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
             if (hipEventRecord(a.h2d_done, ctx->stream) == hipSuccess) a.h2d_valid = true;
             else rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
         }
+#ifdef VO_TEST_HOOKS
         if (!rc && ctx->fault_prefetch > 0 && --ctx->fault_prefetch == 0)
             rc = vo_fail(ctx, VO_E_STATE, "injected failure (VO_FAULT_PREFETCH) inside the engine scope");
-        if (!rc) {
-            // scheme of this pair: with a deep enough queue in front of it the pair is not waited for soon, and the
-            // raster scheme (less than half the HBM traffic, long dependency chain) serves throughput; near the head of
-            // the queue the line scheme (short chains) serves latency.  Same disparity either way.
-            const int saved = ctx->tune_raster, saved_we = ctx->we_now;
-            if (ctx->raster_after >= 0) ctx->tune_raster = ctx->inflight >= ctx->raster_after ? 1 : 0;
-            // likewise the fused horizontal pair (12 % fewer bytes, rows three sweeps long): for pairs behind a queue and
-            // not among the last of the stream
-            if (ctx->tune_we_fuse == 2) ctx->we_now = ctx->inflight >= ctx->we_after && ctx->stream_remaining >= ctx->we_tail;
-            const int saved_band = ctx->band_now;
-            if (ctx->tune_band == 2) ctx->band_now = ctx->inflight >= ctx->we_after && ctx->stream_remaining >= ctx->we_tail;
-            rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
-            ctx->tune_raster = saved;
-            ctx->we_now = saved_we;
-            ctx->band_now = saved_band;
-        }
+#endif
+        if (!rc) rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
         if (!rc && ctx->la_orb) {
             const int* q = ctx->la_orb_params;
             rc = orb_slot_enqueue(ctx, f, q[0], q[1], q[2], q[3]);
@@ -632,13 +617,13 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
     if (rc) {
         // the slot holds a half-processed pair: nothing in it may be handed out
         f.kp_pending = false; f.has_pair = false; f.has_disp = false;
-        if (f.pending && ctx->inflight > 0) ctx->inflight--;
-        f.pending = false;
+        if (f.counted && ctx->inflight > 0) ctx->inflight--;
+        f.counted = false;                               // (`pending` stays: an earlier run into this slot may still be in flight)
         return rc;
     }
     f.has_pair = true; f.has_disp = true;
-    if (!f.pending) ctx->inflight++;
-    f.pending = true;
+    if (!f.counted) ctx->inflight++;
+    f.pending = true; f.counted = true;
     return VO_OK;
 }
 
@@ -677,7 +662,8 @@ extern "C" int vo_prefetch_staged_mono(vo_ctx* ctx, int slot, int index, int nfe
     f.w = w; f.h = h; f.has_kp = false; f.n_kp = 0; f.kp_pending = false; f.has_disp = false;
     {
         EngineScope on_engine(ctx, engine);
-        {
+        rc = slot_before_overwrite(ctx, f);
+        if (!rc) {
             StageTimer t(ctx, VO_T_UPLOAD);
             rc = ingest(ctx, 0, ctx->staged + per * 2 * index, w, h, ctx->staged_ch, 1, f.left, ctx->stage_in, hipMemcpyDeviceToDevice);
         }
@@ -688,13 +674,13 @@ extern "C" int vo_prefetch_staged_mono(vo_ctx* ctx, int slot, int index, int nfe
     }
     if (rc) {
         f.kp_pending = false; f.has_pair = false;
-        if (f.pending && ctx->inflight > 0) ctx->inflight--;
-        f.pending = false;
+        if (f.counted && ctx->inflight > 0) ctx->inflight--;
+        f.counted = false;
         return rc;
     }
     f.has_pair = true;
-    if (!f.pending) ctx->inflight++;
-    f.pending = true;
+    if (!f.counted) ctx->inflight++;
+    f.pending = true; f.counted = true;
     return VO_OK;
 }
 
@@ -913,35 +899,26 @@ extern "C" int vo_get_timings(vo_ctx* ctx, double* ms_out, int64_t* launches_out
     return VO_OK;
 }
 
-extern "C" int vo_sgbm_raster_status(vo_ctx* ctx, int* error_out)
+extern "C" int vo_sgbm_sweep_status(vo_ctx* ctx, int* error_out)
 {
     if (!ctx || !error_out) return VO_E_ARG;
     VO_HIP(ctx, hipSetDevice(ctx->device));
     int rc = vo_synchronize(ctx);
     if (rc) return rc;
-    // word 1 of each control block of every workspace: set (and never cleared) when a wait inside a raster
+    // word 1 of each control block of every workspace: set (and never cleared) when a wait inside a diagonal
     // sweep exceeded its poll limit
     int any = 0;
-    int* blocks[vo_ctx::MAX_ENGINES + 1] = { ctx->rs_ctl };
-    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) blocks[k + 1] = ctx->ws_alt[k].rs_ctl;
+    int* blocks[vo_ctx::MAX_ENGINES + 1] = { ctx->sw_ctl };
+    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) blocks[k + 1] = ctx->ws_alt[k].sw_ctl;
     for (int* b : blocks) {
         if (!b) continue;
         for (int half = 0; half < 2; half++) {
             int v = 0;
-            VO_HIP(ctx, hipMemcpy(&v, b + half * (ctx->rs_ctl_words / 2) + 1, sizeof(int), hipMemcpyDeviceToHost));
+            VO_HIP(ctx, hipMemcpy(&v, b + half * (ctx->sw_ctl_words / 2) + 1, sizeof(int), hipMemcpyDeviceToHost));
             any |= v;
         }
     }
     *error_out = any;
-    if (getenv("VO_RASTER_STATS")) {
-        std::vector<int> h(ctx->rs_ctl_words);
-        VO_HIP(ctx, hipMemcpy(h.data(), ctx->rs_ctl, h.size() * sizeof(int), hipMemcpyDeviceToHost));
-        const int half = ctx->rs_ctl_words / 2;
-        for (int b = 0; b < 2; b++)
-            for (int nb : {2, 8, 90, 192})
-                fprintf(stderr, "raster ctl %d (if %d bands): ticket %d err %d slow_above %d slow_below %d spins %d row_clk64 %d wait_clk64 %d\n", b, nb,
-                        h[b * half], h[b * half + 1], h[b * half + 2], h[b * half + 3], h[b * half + 4 + nb], h[b * half + 4 + nb + 1], h[b * half + 4 + nb + 2]);
-    }
     return VO_OK;
 }
 
@@ -968,10 +945,8 @@ extern "C" int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemp
     if (bytes <= 0 || !ctx->C || !ctx->S) return vo_fail(ctx, VO_E_STATE, "vo_measure_copy: no volumes to copy between");
     VO_HIP(ctx, hipSetDevice(ctx->device));
     // the volumes belong to the main workspace (engine 0 uses it too): nothing of the pipeline may still be running
-    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) {
+    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++)
         if (ctx->la_stream[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream[k]));
-        if (ctx->la_stream_hi[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream_hi[k]));
-    }
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipEvent_t e0, e1;
     VO_HIP(ctx, hipEventCreate(&e0));
@@ -1003,16 +978,25 @@ extern "C" int vo_sgbm_sweep_stats(vo_ctx* ctx, int block, int32_t* out, int n_w
     VO_HIP(ctx, hipSetDevice(ctx->device));
     int rc = vo_synchronize(ctx);
     if (rc) return rc;
-    const int half = ctx->rs_ctl_words / 2;
+    const int half = ctx->sw_ctl_words / 2;
     if (n_words > half) n_words = half;
-    VO_HIP(ctx, hipMemcpy(out, ctx->rs_ctl + block * half, (size_t)n_words * sizeof(int32_t), hipMemcpyDeviceToHost));
+    VO_HIP(ctx, hipMemcpy(out, ctx->sw_ctl + block * half, (size_t)n_words * sizeof(int32_t), hipMemcpyDeviceToHost));
     return VO_OK;
 }
 
-extern "C" int vo_set_stream_hint(vo_ctx* ctx, int pairs_remaining)
+// look-ahead pairs submitted and not yet waited for or dropped (what a per-pair scheduling policy would look at)
+extern "C" int vo_lookahead_depth(vo_ctx* ctx, int* depth_out)
 {
-    if (!ctx) return VO_E_ARG;
-    ctx->stream_remaining = pairs_remaining < 0 ? (1 << 30) : pairs_remaining;
+    if (!ctx || !depth_out) return VO_E_ARG;
+    *depth_out = ctx->inflight;
+    return VO_OK;
+}
+
+// which schedule the latest SGBM run of this context took (VO_SCHED_*)
+extern "C" int vo_sgbm_last_schedule(vo_ctx* ctx, int* schedule_out)
+{
+    if (!ctx || !schedule_out) return VO_E_ARG;
+    *schedule_out = ctx->last_schedule;
     return VO_OK;
 }
 

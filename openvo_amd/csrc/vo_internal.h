@@ -42,6 +42,10 @@ struct FrameSlot {
     // look-ahead: the pair was ingested + SGBM'd on the second stream; `ready` orders consumers
     hipEvent_t ready = nullptr;
     bool pending = false;
+    bool counted = false;        // part of vo_lookahead_depth (submitted, neither waited for nor dropped)
+    // asynchronous pose steps still reading this slot on their own streams (vo_pose_pair_begin): whoever overwrites the slot
+    // orders itself behind them (borrowed events: they belong to the pose alternates and live as long as the context)
+    hipEvent_t readers[2] = {nullptr, nullptr};
     // look-ahead ORB: keypoints were extracted behind the SGBM on the engine's stream; the count lands
     // in the slot's pinned word once `ready` has fired
     int32_t* n_kp_host = nullptr;
@@ -66,15 +70,7 @@ struct vo_ctx {
     // pair's latency-bound kernels overlap another's bandwidth-bound ones)
     static const int MAX_ENGINES = 24;
     hipStream_t la_stream[MAX_ENGINES] = {};
-    // VO_PRIO=1: every engine also owns a HIGH-priority stream; the short latency-bound tail of a pair (median + speckle
-    // filter, ORB chain) hops onto it behind the bandwidth-bound volume kernels, which stay on the (low-priority) engine
-    // stream -- the tail's launches are then dispatched ahead of other pairs' queued volume work
-    hipStream_t la_stream_hi[MAX_ENGINES] = {};
-    hipEvent_t la_hop[MAX_ENGINES] = {};
-    hipStream_t stream_hi = nullptr;   // the current engine's high-priority stream (nullptr on the main stream)
     int cur_engine = -1;
-    bool on_hi = false;
-    int tune_prio = 0;
     uint8_t* la_stage[MAX_ENGINES] = {};
     hipEvent_t sgbm_done = nullptr;  // end of the latest SGBM run in the CURRENT workspace (any stream)
     bool sgbm_done_valid = false;
@@ -83,8 +79,9 @@ struct vo_ctx {
         int16_t *C = nullptr, *S = nullptr, *disp_tmp = nullptr;
         int32_t *ccl_runlen = nullptr, *ccl_label = nullptr, *ccl_size = nullptr;
         int S_vols = 0;
-        uint64_t* rs_bnd = nullptr;
-        int* rs_ctl = nullptr;
+        uint64_t* sw_bnd = nullptr;
+        size_t sw_bnd_bytes = 0;
+        int* sw_ctl = nullptr;
         uint32_t sw_tag = 0;
         hipEvent_t done = nullptr;
         bool done_valid = false;
@@ -131,18 +128,20 @@ struct vo_ctx {
     int S_vols = 0;                // path volumes allocated behind S
     int16_t* disp_tmp = nullptr;   // WTA output before the LR check
     int16_t* dump = nullptr;       // sink for the stores of lanes past the end of their scan line
-    uint64_t* rs_bnd = nullptr;    // raster sweep: bottom-row records handed from band to band (one volume's worth)
-    int* rs_ctl = nullptr;         // raster sweep: two control blocks {ticket, error, -, -, progress[bands]}
-    int rs_ctl_words = 0;
-    uint32_t sw_tag = 0;           // diagonal sweep: launches so far in the current workspace (tag of its boundary granules; 0 = rs_bnd not yet cleared)
-    int tune_diag = 0;             // VO_DIAG: NW / N / NE (+ WTA) as one diagonal sweep over C and the W+E volume (sgbm_diag.inc)
-    int tune_diag_dbg = 0;         // VO_DIAG_DEBUG (development): bit 0 = strips import nothing, bit 1 = export nothing
-    int tune_diag_nwc = 15;        // VO_DIAG_WAVES: compute waves per strip workgroup (7 or 15) for Dp <= 128
+    uint64_t* sw_bnd = nullptr;    // diagonal sweep: boundary granules handed from strip to strip (allocated on first use)
+    size_t sw_bnd_bytes = 0;
+    int* sw_ctl = nullptr;         // diagonal sweep: two control blocks {work items taken, sticky error, ..., per-strip timeline}
+    int sw_ctl_words = 0;
+    uint32_t sw_tag = 0;           // launches so far in the current workspace (tag of its boundary granules)
+    int tune_diag_wgs = 0;         // VO_DIAG_WGS (development): workgroups of one diagonal sweep (0 = one image row's worth of strips + 2)
+    int tune_diag_dbg = 0;         // VO_DIAG_DEBUG (development): bit 0 / 1 = strips import / export nothing, 4 / 8 / 16 / 32 = skip the cost / W+E / diagonal / post stage
+    int tune_diag_nwc = 7;         // VO_DIAG_WAVES: compute waves per strip workgroup (7 or 15) for Dp <= 128
     int32_t* ccl_runlen = nullptr;
     int32_t* ccl_label = nullptr;
     int32_t* ccl_size = nullptr;
     int64_t last_cells = 0;
     int last_paths = 0;
+    int last_schedule = 0;         // VO_SCHED_* of the latest run (vo_sgbm_last_schedule)
 
     // ORB workspace
     OrbLevel lv[VO_ORB_LEVELS];
@@ -205,29 +204,11 @@ struct vo_ctx {
     uint8_t* staged = nullptr;
     int staged_n = 0, staged_w = 0, staged_h = 0, staged_ch = 1;
 
-    // tuning knobs (environment: VO_PATH_PF, VO_SWEEP_XT, VO_SWEEP_TY), read once in vo_create
-    int tune_path_pf = 8, tune_sweep_xt = 8, tune_sweep_ty = 30;
-    int tune_we_fuse = 2;           // VO_WE_FUSE: W and E stored as one volume (E recomputed per 8-column segment from checkpoints):
-                                    // 0 never, 1 always, 2 per pair -- only with >= we_after pairs in flight and >= we_tail pairs still to come
-    int we_after = 4, we_tail = 8;  // VO_WE_AFTER, VO_WE_TAIL
-    int tune_band = 0;              // VO_BAND: 0 never / 1 always / 2 with the per-pair policy of the W+E schedule: N, NW, NE from row checkpoints in 8-row bands (k_sgbm_band)
-    int band_now = 0;
-    int tune_vwta_queued = 16;      // VO_VWTA_QUEUED: lanes per column of the final sweep for pairs the per-pair policy put on the paired schedule (16 / 32)
-    int tune_vwta64 = 0;            // VO_VWTA64: the fused vertical + WTA sweep with 64 lanes per column (MODE_SGBM, Dp = 128 / 256)
-    int tune_pair_hh = 1;           // VO_PAIR_HH: MODE_HH pairs all three opposite direction pairs (k_sgbm_pair), not only W/E
+    // tuning knobs (environment), read once in vo_create and never written afterwards
+    int tune_sweep_ty = 30;         // VO_SWEEP_TY: rows per tile of the cost sweep
     int mono_engine = 0;            // round robin of vo_prefetch_staged_mono
-    int we_now = 0;                 // the decision for the pair being enqueued
-    int stream_remaining = 1 << 30; // vo_set_stream_hint: pairs the caller will still submit after the next one (unknown = many)
-    int tune_path_lanes = 16;       // VO_PATH_LANES: lanes per scan line in k_sgbm_paths (8 = 16 disparities per lane, D <= 128)
-    int fault_prefetch = 0;         // VO_FAULT_PREFETCH=n (test hook): the n-th look-ahead submission fails inside its engine scope
-    int tune_vwta32 = 1;            // VO_VWTA32: the fused vertical + WTA sweep with 32 lanes per column (twice the waves)
-    int tune_fuse_wta = 1;          // VO_FUSE_WTA: last (top-down vertical) path fused with the WTA
-    int raster_after = -1;          // VO_RASTER_AFTER=n: a look-ahead pair runs the raster scheme when n or more pairs are already
-                                    // in flight (both schemes give the same bits: the choice is pure scheduling); -1 = never
-    int inflight = 0;               // look-ahead pairs submitted and not yet waited for
-    int tune_raster_wgs = 16;       // VO_RASTER_WGS: workgroups of one raster sweep (each takes bands off a ticket counter)
-    int tune_raster = 0;            // VO_RASTER=1: W/NW/N/NE (+ WTA) in one raster pass instead of one line sweep per direction
-                                    // (6 instead of 14 volume passes, but a W1 + 2H step dependency chain: slower per pair today)
+    int inflight = 0;               // look-ahead pairs submitted and not yet waited for (vo_lookahead_depth)
+    int fault_prefetch = 0;         // VO_FAULT_PREFETCH=n (VO_TEST_HOOKS builds only): the n-th look-ahead submission fails inside its engine scope
 
     // timing
     bool timing = false;
@@ -273,6 +254,8 @@ int xfer_flush(vo_ctx* ctx);
 
 // make the main stream wait for a slot whose look-ahead work may still be running
 int slot_wait(vo_ctx* ctx, FrameSlot& f);
+// the stream the context currently works on is about to overwrite the slot: order it behind work that still writes or reads it
+int slot_before_overwrite(vo_ctx* ctx, FrameSlot& f);
 int orb_slot_enqueue(vo_ctx* ctx, FrameSlot& f, int nfeatures, int mask_mode, int min_disp16, int max_disp16);
 void pose_alt_free(vo_ctx* ctx);
 size_t pose_ws_bytes(int nq);

@@ -85,6 +85,7 @@ class MonoOdometer:
         self._ctx.stage_pairs([(f, f) for f in frames])
         self._n_staged = len(frames)
         for s in self._ahead.values():
+            self._ctx.lookahead_drop(s)
             self._free.append(s)
         self._ahead = {}
 
@@ -96,8 +97,9 @@ class MonoOdometer:
         if staged and int(img) in self._ahead:
             cur = self._ahead.pop(int(img))                       # extraction already running on an engine
         else:
-            for s in self._ahead.values():                        # out-of-order request: the predictions are void
-                self._free.append(s)
+            for s in self._ahead.values():                        # out-of-order request: the predictions are void (their
+                ctx.lookahead_drop(s)                             # extractions may still run: the native side orders the
+                self._free.append(s)                              # slot's next use behind them)
             self._ahead = {}
             cur = self._free.pop()
             if staged:

@@ -113,12 +113,15 @@ class Group:
 
     def __init__(self, rank, world, master_addr="127.0.0.1", key=None, timeout=300.0):
         self.rank, self.world = int(rank), int(world)
-        self._peers, self._sock, self._mgpu, self._lib = [], None, None, None
+        self._peers, self._sock, self._mgpu, self._lib, self._late = [], None, None, None, None
         self.transport = "socket"
         if self.world == 1:
             return
-        key = key or "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+        key = key or rendezvous_key()
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "vo355_rdzv_%s.json" % key)
+        # the ranks of one node meet on the loopback interface unless told otherwise (VO_RDZV_BIND): nothing outside the
+        # node has any business connecting here, and a launcher's MASTER_ADDR may be a name that does not resolve
+        master_addr = os.environ.get("VO_RDZV_BIND", "127.0.0.1")
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -137,6 +140,9 @@ class Group:
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 conn.settimeout(timeout)
                 (r,) = struct.unpack("<I", _recv_exact(conn, 4))
+                if not (1 <= r < self.world) or r in peers:     # not one of this job's ranks (or one that is already here)
+                    conn.close()
+                    continue
                 peers[r] = conn
             srv.close()
             self._peers = [peers[r] for r in range(1, self.world)]
@@ -184,14 +190,17 @@ class Group:
         return self.all_gather_bytes(payload if self.rank == root else b"")[root]
 
     # -- data plane
-    def attach_rccl(self, device):
+    def attach_rccl(self, device, lib=None):
         """One GPU per rank: route the pose gather through RCCL (vo_mgpu_*).  Returns True on success;
-        on any failure the group stays on the socket transport (every rank takes the same decision)."""
+        on any failure the group stays on the socket transport (every rank takes the same decision: the vote below).
+        lib: the object providing vo_mgpu_* (tests pass a stub; default: the native library)."""
         import ctypes
-        from . import _native
         if self.world == 1:
             return False
-        L = _native.lib()
+        if lib is None:
+            from . import _native
+            lib = _native.lib()
+        L = lib
         ident = (ctypes.c_uint8 * 128)()
         ok = 1
         if self.rank == 0 and L.vo_mgpu_unique_id(ident) != 0:
@@ -215,11 +224,24 @@ class Group:
         rc = res.get("rc", -1)
         oks = self.all_gather_bytes(bytes([1 if rc == 0 else 0]))
         if not all(b == b"\x01" for b in oks):
-            if rc == 0:
+            if th.is_alive():
+                # still inside ncclCommInitRank: the handle belongs to that thread until it returns; close() collects it
+                self._late = (th, h, L, res)
+            elif rc == 0:
                 L.vo_mgpu_destroy(h)
             return False
         self._mgpu, self._lib, self.transport = h, L, "rccl"
         return True
+
+    def describe(self):
+        """What the data plane really is: for RCCL the communicator's own answers (ncclCommCount / ncclCommUserRank)."""
+        import ctypes
+        d = {"transport": self.transport, "world": self.world, "rank": self.rank}
+        if self._mgpu is not None and hasattr(self._lib, "vo_mgpu_info"):
+            n, r, dev = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+            if self._lib.vo_mgpu_info(self._mgpu, ctypes.byref(n), ctypes.byref(r), ctypes.byref(dev)) == 0:
+                d.update({"rccl_ranks": n.value, "rccl_rank": r.value, "device": dev.value})
+        return d
 
     def all_gather_f64(self, local):
         """(n,) float64 per rank (same n everywhere) -> (world, n)."""
@@ -261,6 +283,14 @@ class Group:
         if self._mgpu is not None:
             self._lib.vo_mgpu_destroy(self._mgpu)
             self._mgpu = None
+        if self._late is not None:
+            # a communicator creation that outlived its deadline: if it has returned since, give the communicator back;
+            # if it never does, the daemon thread dies with the process
+            th, h, L, res = self._late
+            th.join(1.0)
+            if not th.is_alive() and res.get("rc", -1) == 0:
+                L.vo_mgpu_destroy(h)
+            self._late = None
         for c in self._peers:
             c.close()
         self._peers = []
@@ -269,6 +299,15 @@ class Group:
             self._sock = None
         if self.rank == 0 and getattr(self, "_path", None) and os.path.exists(self._path):
             os.remove(self._path)
+
+
+def rendezvous_key():
+    """Names the rendezvous file of one job on this node: the launcher's MASTER_ADDR:MASTER_PORT plus its run id when it
+    exports one (torch.distributed.run: TORCHELASTIC_RUN_ID) -- the same for every rank of a job whatever started them
+    (ranks need not share a parent process), different for two jobs on one node."""
+    raw = "%s_%s_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
+                        os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("VO_RUN_ID", "")))
+    return "".join(ch if ch.isalnum() or ch in "._-" else "-" for ch in raw)
 
 
 def device_count():
@@ -287,8 +326,15 @@ def init_from_env(want_rccl=True):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    g = Group(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"))
+    g = Group(rank, world)
     ndev = device_count()
+    masked = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if world > 1 and 0 < ndev < world and not masked and os.environ.get("VO_SHARE_GPU", "0") != "1":
+        # several ranks on one GPU oversubscribe its hardware queues (12 engines each: measured 96 pairs/s instead of 1400);
+        # a launcher that gives every rank a device of its own masks them per rank.  Rehearsals opt in with VO_SHARE_GPU=1.
+        g.close()
+        raise RuntimeError("%d ranks but only %d visible GPU(s) and no per-rank device mask: refusing to share a GPU "
+                           "(set VO_SHARE_GPU=1 for a rehearsal with reduced engines)" % (world, ndev))
     device = local if ndev >= world else local % max(ndev, 1)
     if want_rccl and world > 1 and ndev >= world and os.environ.get("VO_NO_RCCL", "0") != "1":
         g.attach_rccl(device)

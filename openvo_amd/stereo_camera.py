@@ -159,7 +159,7 @@ class StereoCamera:
         if self._lookahead:
             # reclaim the slot held by an unconsumed look-ahead before evicting a live frame
             s = self._lookahead.pop()[1]
-            self._slot_owner[s] = None
+            self._drop(s)
             return s, weakref
         # every slot is still referenced by user code: move the oldest frame to host memory
         # (slots reserved by submit() hold work that cannot be redone and are never taken)
@@ -182,7 +182,7 @@ class StereoCamera:
         Not in the reference: lets a caller overlap / amortise host-to-device ingest."""
         self._ctx.stage_pairs(pairs)
         for hit in self._lookahead:
-            self._slot_owner[hit[1]] = None
+            self._drop(hit[1])
         self._lookahead = []
         self._n_staged = len(pairs)
         return [StagedPair(i) for i in range(len(pairs))]
@@ -209,6 +209,12 @@ class StereoCamera:
         self._slot_owner[slot] = _RESERVED
         return SubmittedPair(slot, shape, preprocessed)
 
+    def _drop(self, slot):
+        """Give back the slot of a look-ahead pair nobody will consume (the native side stops counting it as in flight;
+        whatever still runs on it is ordered before the slot's next use)."""
+        self._slot_owner[slot] = None
+        self._ctx.lookahead_drop(slot)
+
     def slot_key(self, slot):
         """(slot, generation): identifies the pair a slot holds right now."""
         return (slot, self._slot_gen[slot])
@@ -222,7 +228,7 @@ class StereoCamera:
         the pairs will be recomputed when asked for)."""
         self._ctx.synchronize()
         for hit in self._lookahead:
-            self._slot_owner[hit[1]] = None
+            self._drop(hit[1])
         self._lookahead = []
 
     # ---- reference API ----------------------------------------------------------------------
@@ -283,7 +289,7 @@ class StereoCamera:
                 if hit[0] == key:
                     slot, (w, h) = hit[1], hit[2]
                     break
-                self._slot_owner[hit[1]] = None          # stale prediction: give the slot back
+                self._drop(hit[1])                       # stale prediction: give the slot back
         if slot is None:
             slot, _ = self._acquire_slot()
             self._slot_gen[slot] += 1
@@ -308,7 +314,6 @@ class StereoCamera:
                 nxt = self._free_slot()
                 if nxt is None:
                     break
-                self._ctx.set_stream_hint(self._n_staged - 1 - idx)      # pairs still to come after this one
                 shape = self._ctx.prefetch_staged_pair(nxt, idx, preprocessed)
                 self._slot_gen[nxt] += 1
                 self._slot_owner[nxt] = _RESERVED

@@ -66,13 +66,12 @@ def test_c2_pose_chain_default_and_bench_parameters():
         if kw:
             gt = np.linalg.inv(Corridor.gt_pose(20)) @ Corridor.gt_pose(24)
             assert np.linalg.norm(odo.current_pose()[:3, 3] - gt[:3, 3]) < 0.05   # and it does track the corridor
-    assert cam._ctx.sgbm_raster_status() == 0
+    assert cam._ctx.sgbm_sweep_status() == 0 and cam._ctx.sgbm_last_schedule() == _native.SCHED_DIAG
 
 
-def test_c4_full_frame_and_pose_step(monkeypatch):
-    """BASELINE config 4: 2048x1536, 256 disparities, 8-path MODE_HH -- two full frames against the oracle
-    (disparity, keypoints, descriptors bit-exact) and the pose step between them; the first frame also through the
-    pair schedule forced on (three opposite direction pairs stored as one volume each)."""
+def test_c4_full_frame_and_pose_step():
+    """BASELINE config 4: 2048x1536, 256 disparities, 8-path MODE_HH (W + E volume, reverse + forward diagonal sweep) --
+    two full frames against the oracle (disparity, keypoints, descriptors bit-exact) and the pose step between them."""
     from oracle.odometer import RefStereoCamera, RefStereoOdometer
     c = Corridor("C4")
     p = c.sgbm_params(mode=1)
@@ -89,15 +88,9 @@ def test_c4_full_frame_and_pose_step(monkeypatch):
             full = cam.stereoSGBM.compute(L, R)                  # the cv2-object seam on the same frame
             assert np.array_equal(full, rcam.last_disp16)
             assert (full[:, :c.D] == -16).all() and (full >= 0).mean() > 0.5
-            monkeypatch.setenv("VO_WE_FUSE", "1")
-            ctx2 = _native.Context(0, c.w, c.h, c.D, 64)
-            ctx2.set_sgbm(p, 1)
-            paired = ctx2.sgbm_compute_host(L, R)
-            ctx2.close()
-            monkeypatch.delenv("VO_WE_FUSE")
-            assert np.array_equal(paired, full)
     assert np.allclose(odo.c_T_w, rodo.c_T_w, rtol=0, atol=1e-9)
     assert np.linalg.norm(odo.c_T_w[:3, 3]) > 0.1                # the camera did move between the two frames
+    assert cam._ctx.sgbm_sweep_status() == 0 and cam._ctx.sgbm_last_schedule() == _native.SCHED_DIAG
 
 
 @pytest.fixture(scope="module")
@@ -157,106 +150,87 @@ def test_c5_pnp_ransac_8000_points_5000_hypotheses(oracle, c5):
     assert gr["best_count"] > 0.6 * n and np.abs(gr["Rt"][:, 3] - [0.05, -0.02, -0.3]).max() < 0.02
 
 
-@pytest.mark.parametrize("name,mode", [("C1", 0), ("C1", 1)])
-def test_raster_scheme_matches_line_scheme(name, mode, monkeypatch):
-    """VO_RASTER=1 (W/NW/N/NE + WTA in one raster pass, bands chained through HBM hand-offs) gives the same
-    disparity as the default line-per-direction scheme, bit for bit, and its sweeps report no stalled wait."""
-    c = Corridor(name)
-    L, R = c.pair(6)
-    p = c.sgbm_params(mode)
-    out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("VO_RASTER", flag)
-        ctx = _native.Context(0, c.w, c.h, c.D, 64)
-        ctx.set_sgbm(p, mode)
-        out[flag] = ctx.sgbm_compute_host(L, R)
-        assert ctx.sgbm_raster_status() == 0
-        ctx.close()
-    assert np.array_equal(out["0"], out["1"])
+SIZES = [  # name, mode, numDisparities, (w, h) crop or None, compute waves per strip, expected schedule
+    ("T0", 0, 48, None, 7, "diag"),                 # padded disparity range (48 -> Dp 64)
+    ("C1", 0, 64, None, 7, "diag"), ("C1", 1, 64, None, 7, "diag"), ("C1", 0, 64, None, 15, "diag"), ("C1", 1, 64, None, 15, "diag"),
+    ("C1", 0, 112, None, 7, "diag"), ("C1", 1, 112, (632, 471), 15, "diag"),        # 112 -> Dp 128; a height that is no multiple of the unroll
+    ("C1", 0, 96, None, 7, "diag"), ("C1", 0, 32, None, 15, "diag"),               # 3 and 1 registers per lane
+    ("C1", 0, 160, None, 7, "diag"), ("C1", 1, 224, (632, 200), 7, "diag"),         # 5 and 7 registers per lane
+    ("C1", 0, 64, (633, 471), 7, "ragged"), ("C1", 1, 64, (633, 471), 7, "ragged"),  # width - D = 569: W + E by k_sgbm_pair
+    ("C1", 0, 64, (134, 59), 7, "ragged"), ("C1", 1, 112, (200, 59), 7, "diag"),     # lines shorter than two segments; fewer rows than a strip is wide
+    ("C1", 0, 64, (79, 64), 15, "ragged"),                                        # width - D = 15 < one segment
+]
 
 
-@pytest.mark.parametrize("name,mode,ndisp", [("C1", 0, 64), ("C1", 1, 64), ("C2", 0, 128), ("T0", 0, 48), ("C1", 0, 112), ("C1", 1, 112)])
-def test_fused_horizontal_pair_schedule_is_bit_identical(oracle, name, mode, ndisp, monkeypatch):
-    """VO_WE_FUSE=1: W and E stored as ONE volume (E recomputed per 8-column segment from checkpoints, k_sgbm_we) on
-    every frame -- the default policy only picks it for pairs behind a queue, which short test sequences never have.
-    Same disparity as the schedule with separate volumes and as the oracle: MODE_SGBM and MODE_HH, padded and unpadded
-    disparity ranges (112 -> Dp 128, 48 -> Dp 64), C2 at full size."""
+@pytest.mark.parametrize("name,mode,ndisp,crop,waves,sched", SIZES)
+def test_diagonal_schedule_sizes_and_modes(oracle, name, mode, ndisp, crop, waves, sched, monkeypatch):
+    """The aggregation schedule (W + E as one volume, then NW / N / NE + WTA in the diagonal sweep; MODE_HH with the
+    reverse sweep first) against the oracle across register counts, padded disparity ranges, strip widths, ragged widths
+    (k_sgbm_pair instead of k_sgbm_we) and images smaller than a strip."""
     c = Corridor(name)
     L, R = c.pair(4)
-    p = c.sgbm_params(mode)
-    p["numDisparities"] = ndisp
-    out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("VO_WE_FUSE", flag)
-        ctx = _native.Context(0, c.w, c.h, max(c.D, ndisp), 64)
-        ctx.set_sgbm(p, mode)
-        out[flag] = ctx.sgbm_compute_host(L, R)
-        ctx.close()
-    assert (c.w - ndisp) % 8 == 0                                   # otherwise the fused schedule is not taken at all
-    assert np.array_equal(out["0"], out["1"])
-    if name != "C2":                                                # (C2 against the oracle: test_c2_* above)
-        assert np.array_equal(out["1"], oracle.sgbm_compute(L, R, p, mode))
-
-
-@pytest.mark.parametrize("name,ndisp,crop", [("C1", 64, None), ("T0", 48, None), ("C1", 112, (640, 477)), ("C2", 128, None)])
-def test_band_schedule_is_bit_identical(oracle, name, ndisp, crop, monkeypatch):
-    """VO_BAND=1 (opt-in experiment): W + E as one volume, N / NW / NE kept only as one checkpoint row per 8-row band, and
-    k_sgbm_band recomputing them per band in LDS tiles with 8-column halos + the winner search -- same disparity as the
-    default schedule and as the oracle (a height that is not a multiple of 8, padded disparity ranges, C2 at full size)."""
-    c = Corridor(name)
-    L, R = c.pair(5)
     if crop:
         L, R = np.ascontiguousarray(L[:crop[1], :crop[0]]), np.ascontiguousarray(R[:crop[1], :crop[0]])
-    p = c.sgbm_params(0)
+    p = c.sgbm_params(mode)
     p["numDisparities"] = ndisp
-    out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("VO_BAND", flag)
-        monkeypatch.setenv("VO_WE_FUSE", "0")
-        ctx = _native.Context(0, c.w, c.h, max(c.D, ndisp), 64)
-        ctx.set_sgbm(p, 0)
-        out[flag] = ctx.sgbm_compute_host(L, R)
-        ctx.close()
-    assert np.array_equal(out["0"], out["1"])
-    if name != "C2":
-        assert np.array_equal(out["1"], oracle.sgbm_compute(L, R, p, 0))
+    monkeypatch.setenv("VO_DIAG_WAVES", str(waves))
+    h, w = L.shape
+    ctx = _native.Context(0, max(w, 64), max(h, 64), max(16, ndisp), 64)
+    ctx.set_sgbm(p, mode)
+    got = ctx.sgbm_compute_host(L, R)
+    again = ctx.sgbm_compute_host(L, R)                           # the boundary granules of the first run must not leak into the second
+    status, schedule = ctx.sgbm_sweep_status(), ctx.sgbm_last_schedule()
+    ctx.close()
+    ref = oracle.sgbm_compute(L, R, p, mode)
+    assert status == 0
+    assert schedule == (_native.SCHED_DIAG if sched == "diag" else _native.SCHED_DIAG_RAGGED)
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    assert np.array_equal(again, ref)
 
 
-def test_sweep_with_64_lanes_per_column_is_bit_identical(monkeypatch):
-    """VO_VWTA64=1 (opt-in): the fused vertical + WTA sweep with one column per wave (1152 waves at C2, more than one per
-    SIMD -- what the round-1 review asked to try; slower as measured, kept under test): C2 frame, both schedules."""
-    c = Corridor("C2")
-    L, R = c.pair(7)
-    p = c.sgbm_params(0)
-    out = {}
-    for tag, env in (("ref", {"VO_VWTA64": "0", "VO_WE_FUSE": "0"}), ("v64", {"VO_VWTA64": "1", "VO_WE_FUSE": "0"}), ("v64we", {"VO_VWTA64": "1", "VO_WE_FUSE": "1"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        ctx = _native.Context(0, c.w, c.h, c.D, 64)
-        ctx.set_sgbm(p, 0)
-        out[tag] = ctx.sgbm_compute_host(L, R)
-        ctx.close()
-    assert np.array_equal(out["ref"], out["v64"]) and np.array_equal(out["ref"], out["v64we"])
-
-
-def test_pair_schedule_on_ragged_sizes(oracle, monkeypatch):
-    """MODE_HH with the pair schedule forced (k_sgbm_pair: W/E, NW/SE, NE/SW each stored as one volume): image sizes
-    that make every diagonal a different length and leave partial 8-step segments everywhere (width1 = 569, height 471;
-    a 70 x 59 image whose lines are shorter than two segments), padded disparity range -- against the oracle."""
-    c = Corridor("C1")
+@pytest.mark.parametrize("mode", [0, 1])
+def test_uniqueness_ratio_100_takes_the_unfused_schedule(oracle, mode):
+    """uniquenessRatio >= 100 has no threshold form: one stored volume per direction (k_sgbm_paths) and the per-pixel
+    winner search (k_sgbm_wta) -- against the oracle, and back to the fused schedule on the same context."""
+    c = Corridor("T0")
     L, R = c.pair(3)
-    for (w, h, ndisp) in ((633, 471, 64), (134, 59, 64), (640, 480, 112)):
-        l, r = np.ascontiguousarray(L[:h, :w]), np.ascontiguousarray(R[:h, :w])
-        p = c.sgbm_params(1)
-        p["numDisparities"] = ndisp
-        ref = oracle.sgbm_compute(l, r, p, 1)
-        for flag in ("0", "1"):
-            monkeypatch.setenv("VO_WE_FUSE", flag)
-            ctx = _native.Context(0, max(w, 64), max(h, 64), ndisp, 64)
-            ctx.set_sgbm(p, 1)
-            got = ctx.sgbm_compute_host(l, r)
-            ctx.close()
-            assert np.array_equal(got, ref), (w, h, ndisp, flag, int((got != ref).sum()))
+    p = c.sgbm_params(mode)
+    p["uniquenessRatio"] = 100
+    ctx = _native.Context(0, c.w, c.h, c.D, 64)
+    ctx.set_sgbm(p, mode)
+    got = ctx.sgbm_compute_host(L, R)
+    assert ctx.sgbm_last_schedule() == _native.SCHED_UNFUSED
+    assert np.array_equal(got, oracle.sgbm_compute(L, R, p, mode))
+    p["uniquenessRatio"] = 99                                     # 100 - ur = 1: the reciprocal's special case
+    ctx.set_sgbm(p, mode)
+    got = ctx.sgbm_compute_host(L, R)
+    assert ctx.sgbm_last_schedule() == _native.SCHED_DIAG
+    assert np.array_equal(got, oracle.sgbm_compute(L, R, p, mode))
+    ctx.close()
+
+
+def test_c2_stream_of_24_pairs_default_policy_every_pair_against_the_oracle():
+    """What the headline bench runs: a staged C2 stream through StereoOdometer with the default look-ahead (pairs computed
+    ahead on the engines, each with the diagonal schedule) -- EVERY pair's disparity, keypoints and descriptors against
+    the oracle, the chained pose to 1e-9."""
+    from oracle.odometer import RefStereoCamera, RefStereoOdometer
+    c = Corridor("C2")
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=500)
+    rcam = RefStereoCamera(cam.Q, cam.valid_region_left, c.sgbm_params())
+    kw = dict(preprocessed_frames=True, rigidity_threshold=0.1, outlier_threshold=0.02)
+    odo, rodo = StereoOdometer(cam, **kw), RefStereoOdometer(rcam, **kw)
+    frames = c.pairs(30, 24)
+    staged = cam.stage_pairs(frames)
+    depth_seen = 0
+    for k, (L, R) in enumerate(frames):
+        a, b = odo.update(staged[k], None), rodo.update(L, R)
+        depth_seen = max(depth_seen, cam._ctx.lookahead_depth())
+        assert a == b and odo.skip_cause == rodo.skip_cause, k
+        if a:
+            _check_frame(odo, rodo, rcam, cam, k)
+        assert np.allclose(odo.c_T_w, rodo.c_T_w, rtol=0, atol=1e-9), k
+    assert depth_seen >= 4                                        # pairs really were computed ahead, behind a queue
+    assert cam._ctx.sgbm_last_schedule() == _native.SCHED_DIAG and cam._ctx.sgbm_sweep_status() == 0
 
 
 def test_c5_mono_pair_device_chain_and_odometer(oracle, c5):
@@ -335,3 +309,30 @@ def test_mono_lookahead_gives_the_same_chain():
     for (a, ca, la, Ta), (b, cb, lb, Tb) in zip(chains[0], chains[3]):
         assert a == b and ca == cb and la == lb and np.array_equal(Ta, Tb)
     assert sum(x[0] for x in chains[3]) >= 6
+
+
+def test_mono_unpredicted_request_while_predictions_are_in_flight():
+    """update(0) starts the extraction of frames 1..3 on look-ahead engines; update(5) -- a frame nobody predicted -- voids
+    them while they may still be running and immediately reuses one of their slots on another stream.  The slot's next use
+    must be ordered behind the voided extraction (vo_prefetch_staged_mono / the upload wait for the slot's `ready` event):
+    the chain equals the one-frame-at-a-time run."""
+    from openvo_amd.mono import MonoOdometer
+    c = Corridor("C5")
+    K = np.array([[c.f, 0, c.cx], [0, c.f, c.cy], [0, 0, 1.0]])
+    frames = [c.pair(k)[0] for k in range(8)]
+    order = [0, 5, 6, 2, 7, 3]                                         # every second request is one the look-ahead did not predict
+    chains = {}
+    for depth in (0, 3):
+        odo = MonoOdometer(K, (c.w, c.h), nfeatures=3000, ransac_iters=1500)
+        odo.lookahead = depth
+        odo.stage_frames(frames)
+        chain = []
+        for k in order:
+            ok = odo.update(k)
+            n = odo._ctx.orb_slot_count(odo._ref[0], odo.nfeatures, 0)
+            chain.append((ok, odo.skip_cause, n, None if odo.last is None else (odo.last["matches"], odo.last["best_count"]), odo.c_T_w.copy()))
+        chains[depth] = chain
+        assert odo._ctx.lookahead_depth() <= depth
+        odo._ctx.close()
+    for (a, ca, na, la, Ta), (b, cb, nb, lb, Tb) in zip(chains[0], chains[3]):
+        assert a == b and ca == cb and na == nb and la == lb and np.array_equal(Ta, Tb)

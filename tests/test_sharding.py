@@ -245,3 +245,93 @@ def test_single_process_group_is_the_identity():
     assert g.all_reduce_max(2.5) == 2.5 and g.all_gather_bytes(b"x") == [b"x"]
     b, ok2 = sharding.gather_relative(T, [1, 1, 1])
     assert b.shape == (3, 4, 4) and ok2.all()
+
+
+# ---- communicator creation: every rank takes the same decision ------------------------------------------------
+_VOTE = r'''
+import ctypes, os, sys
+from openvo_amd import sharding
+
+
+class StubRccl:
+    """vo_mgpu_* of a library whose communicator creation fails on one rank (argv[1]) -- no GPU, no RCCL involved."""
+    def __init__(self, bad_rank):
+        self.bad, self.destroyed, self.created = bad_rank, 0, 0
+    def vo_mgpu_unique_id(self, ident):
+        ident[0] = 42
+        return 0
+    def vo_mgpu_create(self, device, rank, world, ident, out):
+        assert ident[0] == 42 and world == int(os.environ["WORLD_SIZE"])
+        if rank == self.bad:
+            return -3
+        self.created += 1
+        return 0
+    def vo_mgpu_destroy(self, h):
+        self.destroyed += 1
+
+
+bad = int(sys.argv[1])
+g = sharding.Group(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
+stub = StubRccl(bad)
+took = g.attach_rccl(0, lib=stub)
+assert took == (bad < 0), took                       # one rank failing makes EVERY rank stay on the sockets
+assert g.transport == ("rccl" if bad < 0 else "socket")
+if bad >= 0 and g.rank != bad:
+    assert stub.created == 1 and stub.destroyed == 1  # a communicator that was created is given back
+assert g.describe()["transport"] == g.transport and g.describe()["world"] == g.world
+if bad >= 0:
+    assert g.all_reduce_max(1.0 + g.rank) == float(g.world)   # the socket transport carries on
+g._mgpu = None                                        # (the stub has no collectives to close)
+g.close()
+print("VOTE_OK")
+'''
+
+
+@pytest.mark.parametrize("bad", [1, 0, -1])
+def test_rccl_attach_vote_falls_back_together(tmp_path, bad):
+    """attach_rccl with a stub library: communicator creation failing on one rank (a peer, or rank 0) leaves all three
+    ranks on the socket transport, creation succeeding everywhere switches all three."""
+    outs = _spawn(_VOTE, 3, tmp_path, args=(bad,))
+    assert all("VOTE_OK" in o for o in outs)
+
+
+def test_rendezvous_key_is_shared_by_a_job_and_differs_between_jobs(monkeypatch):
+    """The rendezvous file is named after MASTER_ADDR:MASTER_PORT and the launcher's run id, not after a parent pid:
+    ranks started by different parents find each other, two jobs on one node do not collide."""
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    monkeypatch.delenv("VO_RUN_ID", raising=False)
+    k0 = sharding.rendezvous_key()
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job/A")
+    ka = sharding.rendezvous_key()
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job/B")
+    kb = sharding.rendezvous_key()
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    kc = sharding.rendezvous_key()
+    assert len({k0, ka, kb, kc}) == 4 and all("/" not in k and str(os.getppid()) not in k.split("_")[-1:] for k in (k0, ka, kb, kc))
+
+
+def test_more_ranks_than_gpus_is_refused_without_a_mask(monkeypatch):
+    """init_from_env: ranks outnumbering the visible GPUs without a per-rank device mask is an error (shared hardware
+    queues collapse the rate), unless the rehearsal switch is set."""
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(sharding, "device_count", lambda: 1)
+    g, dev = sharding.init_from_env()                   # one rank, one GPU: fine
+    g.close()
+
+    class FakeGroup:
+        def __init__(self, rank, world):
+            self.rank, self.world, self.closed = rank, world, False
+        def close(self):
+            self.closed = True
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sharding, "Group", FakeGroup)
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "VO_SHARE_GPU"):
+        monkeypatch.delenv(v, raising=False)
+    with pytest.raises(RuntimeError, match="refusing to share a GPU"):
+        sharding.init_from_env()
+    monkeypatch.setenv("VO_SHARE_GPU", "1")
+    g, dev = sharding.init_from_env(want_rccl=False)
+    assert dev == 0 and g.world == 2

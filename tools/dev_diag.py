@@ -23,7 +23,7 @@ def run(c, L, R, p, mode, env, reps=0):
     ctx = _native.Context(0, max(w, 64), max(h, 64), max(16, (p["numDisparities"] + 15) // 16 * 16), 64)
     ctx.set_sgbm(p, mode)
     out = ctx.sgbm_compute_host(L, R)
-    st = ctx.sgbm_raster_status()
+    st = ctx.sgbm_sweep_status()
     tm = None
     if reps:
         ctx.enable_timing(True, ["sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post"])
