@@ -204,6 +204,8 @@ def bench_stereo(args, group, device, workload, K, W, light):
             try:
                 tj = json.load(open(tf))
                 traffic, per_pair = tj.get("dominant_kernel_bytes_per_launch"), tj.get("sgbm_bytes_per_pair")
+                if not isinstance(per_pair, (int, float)):        # (a profile file of an older layout)
+                    per_pair = None
             except Exception:
                 traffic = per_pair = None
         roof = {"bound": "hbm",

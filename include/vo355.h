@@ -83,6 +83,17 @@ int vo_lookahead_drop(vo_ctx* ctx, int slot);
  * buffers are free again when the call returns. */
 int vo_prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* left, const uint8_t* right, int w, int h,
                      int channels, int preprocessed);
+/* the same in two halves, so that the thread that launches kernels does no memcpy (the reference hands host arrays to
+ * update(), stereo_odometer.py:115-116): vo_host_stage_pair copies the two images into pinned staging buffer `buf`
+ * (0 .. VO_NUM_HOST_STAGE-1) -- it first waits until the previous upload out of that buffer has finished, and it is the ONE
+ * entry point that may run on another thread while the context is in use (it touches nothing but that buffer; two calls
+ * must not name the same buffer concurrently); vo_prefetch_host_staged then starts upload + SGBM (+ ORB) of that buffer's
+ * pair on a look-ahead engine like vo_prefetch_pair.  openvo_amd.StereoOdometer.run() drives them from a helper thread. */
+#define VO_NUM_HOST_STAGE 16
+int vo_host_stage_pair(vo_ctx* ctx, int buf, const uint8_t* left, const uint8_t* right, int w, int h, int channels);
+int vo_prefetch_host_staged(vo_ctx* ctx, int slot, int buf, int w, int h, int channels, int preprocessed);
+/* the pair staging buffer `buf` holds, copied back out (a caller that found no free slot keeps the pair on the host) */
+int vo_host_stage_fetch(vo_ctx* ctx, int buf, uint8_t* left, uint8_t* right, int w, int h, int channels);
 /* look-ahead keypoints: when enabled, every vo_prefetch_staged_pair also runs the ORB extraction
  * (same arguments as vo_orb_detect_and_compute) behind the SGBM on the engine's stream; a later
  * vo_orb_detect_and_compute on that slot with the SAME arguments only waits and downloads, any

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("VO355_LIB") or os.path.join(_HERE, "libvo355.so")   #
 _CSRC = os.path.join(_HERE, "csrc")
 
 VO_NUM_SLOTS = 28
+VO_NUM_HOST_STAGE = 16
 SCHED_DIAG, SCHED_DIAG_RAGGED, SCHED_UNFUSED = 1, 2, 3
 T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose")
 
@@ -28,7 +29,7 @@ SYMBOLS = [
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints", "vo_download_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_essential5", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
-    "vo_sgbm_last_geometry", "vo_lookahead_depth", "vo_lookahead_drop", "vo_sgbm_last_schedule", "vo_measure_copy", "vo_sgbm_sweep_status", "vo_sgbm_sweep_stats",
+    "vo_sgbm_last_geometry", "vo_host_stage_pair", "vo_host_stage_fetch", "vo_prefetch_host_staged", "vo_lookahead_depth", "vo_lookahead_drop", "vo_sgbm_last_schedule", "vo_measure_copy", "vo_sgbm_sweep_status", "vo_sgbm_sweep_stats",
     "vo_upload_mono", "vo_prefetch_staged_mono", "vo_mono_pair",
     "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_info", "vo_mgpu_last_error",
     "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
@@ -117,6 +118,9 @@ def lib():
         L.vo_sgbm_last_geometry.argtypes = [vp, vp, vp]
         L.vo_sgbm_sweep_status.argtypes = [vp, vp]
         L.vo_lookahead_depth.argtypes = [vp, vp]
+        L.vo_host_stage_pair.argtypes = [vp, ci, vp, vp, ci, ci, ci]
+        L.vo_host_stage_fetch.argtypes = [vp, ci, vp, vp, ci, ci, ci]
+        L.vo_prefetch_host_staged.argtypes = [vp, ci, ci, ci, ci, ci, ci]
         L.vo_lookahead_drop.argtypes = [vp, ci]
         L.vo_sgbm_last_schedule.argtypes = [vp, vp]
         L.vo_sgbm_sweep_stats.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
@@ -219,6 +223,27 @@ class Context:
         left, right = _c(left, np.uint8), _c(right, np.uint8)
         h, w = left.shape[:2]
         self._ck(self._lib.vo_prefetch_pair(self._h, slot, _p(left), _p(right), w, h, ch, int(bool(preprocessed))))
+        return w, h
+
+    def host_stage_pair(self, buf, left, right):
+        """Copy a host pair into pinned staging buffer `buf` (waits for that buffer's previous upload).  The one call that
+        may run on a helper thread while another thread drives this context."""
+        ch = 3 if left.ndim == 3 else 1
+        left, right = _c(left, np.uint8), _c(right, np.uint8)
+        h, w = left.shape[:2]
+        rc = self._lib.vo_host_stage_pair(self._h, int(buf), _p(left), _p(right), w, h, ch)
+        if rc != 0:
+            raise VoError(rc, "vo_host_stage_pair failed")      # (the context's error string belongs to the driving thread)
+        return w, h, ch
+
+    def host_stage_fetch(self, buf, w, h, ch):
+        shape = (h, w, 3) if ch == 3 else (h, w)
+        left, right = np.empty(shape, np.uint8), np.empty(shape, np.uint8)
+        self._ck(self._lib.vo_host_stage_fetch(self._h, int(buf), _p(left), _p(right), w, h, ch))
+        return left, right
+
+    def prefetch_host_staged(self, slot, buf, w, h, ch, preprocessed):
+        self._ck(self._lib.vo_prefetch_host_staged(self._h, slot, int(buf), w, h, ch, int(bool(preprocessed))))
         return w, h
 
     def stage_pairs(self, pairs):

@@ -164,8 +164,10 @@ __device__ __forceinline__ uint32_t bt_regs(uint32_t lw0, uint32_t lw1, const ui
     for (int c = 0; c < 2; c++) {
         const uint32_t lw = c ? lw1 : lw0;
         const uint32_t U = pk_rep(lw & 255), U0 = pk_rep((lw >> 8) & 255), U1 = pk_rep((lw >> 16) & 255);
-        const uint32_t c0 = pk_max(pk_max(pk_sub(U, V[c * 3 + 2]), pk_sub(V[c * 3 + 1], U)), 0u);
-        const uint32_t c1 = pk_max(pk_max(pk_sub(V[c * 3 + 0], U1), pk_sub(U0, V[c * 3 + 0])), 0u);
+        // distance of a value to an interval [lo, hi], lo <= hi, all in 0..255: at most one of (x - hi), (lo - x) is positive,
+        // so max(0, x - hi, lo - x) = usat(x - hi) | usat(lo - x)  (3 packed operations instead of 4)
+        const uint32_t c0 = pk_sub_sat_u(U, V[c * 3 + 2]) | pk_sub_sat_u(V[c * 3 + 1], U);
+        const uint32_t c1 = pk_sub_sat_u(V[c * 3 + 0], U1) | pk_sub_sat_u(U0, V[c * 3 + 0]);
         uint32_t m = pk_min(c0, c1);
         if (c == 1) m = (m >> 2) & 0x3FFF3FFFu;
         acc = pk_add(acc, m);
@@ -1146,6 +1148,10 @@ static int launch_diag(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int16
         if (ctx->tune_diag_nwc == 15)
             return pad ? launch_diag_k<NP, true, 15, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 15, REV, WTA>(ctx, g, in1, sout, ctl);
     }
+#ifdef VO_DIAG_NWC3
+    if (ctx->tune_diag_nwc == 3)
+        return pad ? launch_diag_k<NP, true, 3, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 3, REV, WTA>(ctx, g, in1, sout, ctl);
+#endif
     return pad ? launch_diag_k<NP, true, 7, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 7, REV, WTA>(ctx, g, in1, sout, ctl);
 }
 

@@ -204,7 +204,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     }
     if (const char* e27 = getenv("VO_DIAG_WGS")) ctx->tune_diag_wgs = atoi(e27);
     if (const char* e26 = getenv("VO_DIAG_DEBUG")) ctx->tune_diag_dbg = atoi(e26);
-    if (const char* e25 = getenv("VO_DIAG_WAVES")) ctx->tune_diag_nwc = atoi(e25) == 15 ? 15 : 7;
+    if (const char* e25 = getenv("VO_DIAG_WAVES")) { const int v = atoi(e25); ctx->tune_diag_nwc = (v == 15 || v == 3) ? v : 7; }
 #ifdef VO_TEST_HOOKS
     if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);   // test-only build (libvo355_hooks.so)
 #endif
@@ -246,6 +246,10 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         if (a.pinned) (void)hipHostFree(a.pinned);
         if (a.h2d_done) (void)hipEventDestroy(a.h2d_done);
         if (ctx->la_stream[k]) (void)hipStreamDestroy(ctx->la_stream[k]);
+    }
+    for (vo_ctx::HostStage& hs : ctx->host_stage) {
+        if (hs.pinned) (void)hipHostFree(hs.pinned);
+        if (hs.h2d_done) (void)hipEventDestroy(hs.h2d_done);
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -565,7 +569,7 @@ int slot_before_overwrite(vo_ctx* ctx, FrameSlot& f)
 // common tail of the look-ahead entry points: ingest (device or pinned-host source) + SGBM (+ ORB) of one
 // pair on the next engine's stream, `ready` recorded at the end
 static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8_t* srcR, bool from_host, int w, int h,
-                         int channels, int preprocessed)
+                         int channels, int preprocessed, vo_ctx::HostStage* hs = nullptr)
 {
     int rc;
     FrameSlot& f = ctx->slots[slot];
@@ -573,7 +577,9 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
     if ((rc = engine_prepare(ctx, engine))) return rc;
     const size_t per = (size_t)w * h * channels;
     hipMemcpyKind kind = hipMemcpyDeviceToDevice;
-    if (from_host) {
+    if (hs) {
+        kind = hipMemcpyHostToDevice;                 // pinned staging filled ahead by vo_host_stage_pair
+    } else if (from_host) {
         // user memory -> this engine's pinned buffer (plain memcpy) -> async H2D on the engine's stream;
         // the buffer is reused only after the previous copy out of it has finished
         vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
@@ -597,7 +603,10 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
             rc = ingest(ctx, 0, srcL, w, h, channels, preprocessed, f.left, ctx->stage_in, kind);
             if (!rc) rc = ingest(ctx, 1, srcR, w, h, channels, preprocessed, f.right, ctx->stage_in, kind);
         }
-        if (!rc && from_host) {
+        if (!rc && hs) {
+            if (hipEventRecord(hs->h2d_done, ctx->stream) == hipSuccess) hs->valid = true;
+            else rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
+        } else if (!rc && from_host) {
             vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
             if (hipEventRecord(a.h2d_done, ctx->stream) == hipSuccess) a.h2d_valid = true;
             else rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
@@ -696,6 +705,56 @@ extern "C" int vo_prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* left, cons
     if (!ctx->sg.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");
     VO_HIP(ctx, hipSetDevice(ctx->device));
     return prefetch_pair(ctx, slot, left, right, true, w, h, channels, preprocessed);
+}
+
+// May run on a helper thread of the caller while another thread drives the context: it touches nothing but staging
+// buffer `buf` (and reports failures by code only: the context's error string belongs to the driving thread).
+extern "C" int vo_host_stage_pair(vo_ctx* ctx, int buf, const uint8_t* left, const uint8_t* right, int w, int h, int channels)
+{
+    if (!ctx || buf < 0 || buf >= vo_ctx::N_HOST_STAGE || !left || !right || (channels != 1 && channels != 3)) return VO_E_ARG;
+    if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return VO_E_CAP;
+    if (hipSetDevice(ctx->device) != hipSuccess) return VO_E_HIP;
+    vo_ctx::HostStage& hs = ctx->host_stage[buf];
+    if (!hs.pinned) {
+        // first use of the staging path: every buffer at once (a pinned allocation takes about a millisecond -- not something
+        // to pay inside a stream, buffer by buffer); only the thread that stages ever gets here
+        for (vo_ctx::HostStage& q : ctx->host_stage) {
+            if (q.pinned) continue;
+            if (hipHostMalloc((void**)&q.pinned, ctx->stage_bytes * 2, hipHostMallocDefault) != hipSuccess) return VO_E_HIP;
+            if (hipEventCreateWithFlags(&q.h2d_done, hipEventDisableTiming) != hipSuccess) return VO_E_HIP;
+        }
+    }
+    if (hs.valid && hipEventSynchronize(hs.h2d_done) != hipSuccess) return VO_E_HIP;   // the previous upload out of this buffer
+    const size_t per = (size_t)w * h * channels;
+    memcpy(hs.pinned, left, per);
+    memcpy(hs.pinned + per, right, per);
+    return VO_OK;
+}
+
+// the pair a staging buffer holds, copied back out (the caller found no free slot for it and keeps it on the host)
+extern "C" int vo_host_stage_fetch(vo_ctx* ctx, int buf, uint8_t* left, uint8_t* right, int w, int h, int channels)
+{
+    if (!ctx || buf < 0 || buf >= vo_ctx::N_HOST_STAGE || !left || !right || (channels != 1 && channels != 3)) return VO_E_ARG;
+    vo_ctx::HostStage& hs = ctx->host_stage[buf];
+    if (!hs.pinned || (size_t)w * h * channels > ctx->stage_bytes) return VO_E_STATE;
+    const size_t per = (size_t)w * h * channels;
+    memcpy(left, hs.pinned, per);
+    memcpy(right, hs.pinned + per, per);
+    return VO_OK;
+}
+
+extern "C" int vo_prefetch_host_staged(vo_ctx* ctx, int slot, int buf, int w, int h, int channels, int preprocessed)
+{
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (buf < 0 || buf >= vo_ctx::N_HOST_STAGE || (channels != 1 && channels != 3)) return vo_fail(ctx, VO_E_ARG, "vo_prefetch_host_staged: bad argument");
+    if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context %dx%d", w, h, ctx->max_w, ctx->max_h);
+    if (!ctx->sg.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");
+    vo_ctx::HostStage& hs = ctx->host_stage[buf];
+    if (!hs.pinned) return vo_fail(ctx, VO_E_STATE, "staging buffer %d has not been filled (vo_host_stage_pair)", buf);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t per = (size_t)w * h * channels;
+    return prefetch_pair(ctx, slot, hs.pinned, hs.pinned + per, true, w, h, channels, preprocessed, &hs);
 }
 
 extern "C" int vo_set_lookahead_orb(vo_ctx* ctx, int enable, int nfeatures, int mask_mode, int min_disp16, int max_disp16)

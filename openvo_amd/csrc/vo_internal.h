@@ -200,6 +200,11 @@ struct vo_ctx {
     struct PendingCopy { void* dst; const void* src; size_t bytes; };
     std::vector<PendingCopy> pending;  // device->host copies staged in the arena, scattered at flush
 
+    // pinned staging buffers for host images filled AHEAD by a helper thread of the caller (vo_host_stage_pair) and consumed by
+    // vo_prefetch_host_staged on the thread that drives the context: the launching thread does no memcpy
+    static const int N_HOST_STAGE = VO_NUM_HOST_STAGE;
+    struct HostStage { uint8_t* pinned = nullptr; hipEvent_t h2d_done = nullptr; bool valid = false; } host_stage[VO_NUM_HOST_STAGE];
+
     // inputs staged in HBM
     uint8_t* staged = nullptr;
     int staged_n = 0, staged_w = 0, staged_h = 0, staged_ch = 1;

@@ -209,6 +209,20 @@ class StereoCamera:
         self._slot_owner[slot] = _RESERVED
         return SubmittedPair(slot, shape, preprocessed)
 
+    def submit_staged(self, buf, w, h, ch, preprocessed):
+        """Second half of submit() for a pair that a helper thread has already copied into pinned staging buffer `buf`
+        (Context.host_stage_pair): upload + disparity (+ keypoints) start on a look-ahead engine, nothing is copied on
+        this thread.  With no free slot the pair is taken back out of the staging buffer and processed synchronously when
+        consumed, like submit() (the caller's own arrays may have been reused by then)."""
+        held = sum(1 for o in self._slot_owner if o is _RESERVED)
+        slot = self._free_slot() if held < _native.VO_NUM_SLOTS - 3 else None
+        if slot is None:
+            return SubmittedPair(None, None, preprocessed, self._ctx.host_stage_fetch(buf, w, h, ch))
+        shape = self._ctx.prefetch_host_staged(slot, buf, w, h, ch, preprocessed)
+        self._slot_gen[slot] += 1
+        self._slot_owner[slot] = _RESERVED
+        return SubmittedPair(slot, shape, preprocessed)
+
     def _drop(self, slot):
         """Give back the slot of a look-ahead pair nobody will consume (the native side stops counting it as in flight;
         whatever still runs on it is ordered before the slot's next use)."""

@@ -8,6 +8,7 @@ so it follows the reference decision for decision (pinned by tests/golden/g5_sta
 """
 import numpy as np
 
+from . import _native
 from .features import BFMatcher, DeviceImage, DisparityMask, KeyPointList, ORB
 
 
@@ -171,25 +172,67 @@ class StereoOdometer:
 
     def run(self, pairs, depth=None):
         """Feed an iterable of host (left, right) pairs through update(), keeping up to `depth` pairs
-        submitted ahead (StereoCamera.submit) so their upload and disparity overlap the tracking of
-        the current pair.  Yields update()'s result per pair, in order.  Not in the reference."""
+        submitted ahead so their upload and disparity overlap the tracking of the current pair.  Yields
+        update()'s result per pair, in order.  Not in the reference (whose update() takes one host pair per call,
+        stereo_odometer.py:115-116).
+
+        The copy of each pair into pinned staging memory runs on a helper thread (the native call releases the GIL), a few
+        pairs ahead, so the thread that launches kernels never touches image bytes; pairs whose two images differ in
+        channel count go through StereoCamera.submit() instead."""
+        import queue as _queue
+        import threading
         from collections import deque
-        depth = int(self.stereo.lookahead if depth is None else depth)
-        it, queue = iter(pairs), deque()
-        while True:
-            while len(queue) <= depth:
-                nxt = next(it, None)
-                if nxt is None:
-                    break
-                queue.append(self.stereo.submit(nxt[0], nxt[1], preprocessed=self.preprocessed_frames))
-            if not queue:
-                return
-            head = queue.popleft()
-            self._next_hint = tuple(queue)[:2]
+        cam, ctx = self.stereo, self.stereo._ctx
+        depth = int(cam.lookahead if depth is None else depth)
+        nbuf = _native.VO_NUM_HOST_STAGE
+        staged, free, stop = _queue.Queue(), threading.Semaphore(nbuf - 1), threading.Event()
+
+        def stager():
             try:
-                yield self.update(head, None)
+                for k, (L, R) in enumerate(pairs):
+                    L, R = np.asarray(L), np.asarray(R)
+                    if L.ndim != R.ndim or L.shape != R.shape:
+                        staged.put((None, L.copy(), R.copy()))   # mixed inputs: the driving thread converts them
+                        continue
+                    free.acquire()                               # a buffer whose previous pair has been handed to the engines
+                    if stop.is_set():
+                        return
+                    staged.put((ctx.host_stage_pair(k % nbuf, L, R), k % nbuf, None))
+            except BaseException as e:                           # surfaces on the consuming thread
+                staged.put(e)
             finally:
-                self._next_hint = ()
+                staged.put(None)
+
+        th = threading.Thread(target=stager, name="vo355-host-stager", daemon=True)
+        th.start()
+        queue, done = deque(), False
+        try:
+            while True:
+                while len(queue) <= depth and not done:
+                    item = staged.get()
+                    if item is None:
+                        done = True
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    tok, a, b = item
+                    if tok is None:
+                        queue.append(cam.submit(a, b, preprocessed=self.preprocessed_frames))
+                    else:
+                        queue.append(cam.submit_staged(a, tok[0], tok[1], tok[2], self.preprocessed_frames))
+                        free.release()                           # (its upload is queued; the stager waits for it before reusing the buffer)
+                if not queue:
+                    return
+                head = queue.popleft()
+                self._next_hint = tuple(queue)[:2]
+                try:
+                    yield self.update(head, None)
+                finally:
+                    self._next_hint = ()
+        finally:
+            stop.set()
+            free.release()
+            th.join(timeout=30.0)
 
     _SEAMS = ("point_clouds", "point_cloud_transform", "rigid_body_filter", "bilinear_interpolate_pixels",
               "_estimate", "_gate")

@@ -10,14 +10,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libvo_oracle.so")
+_LIB = os.environ.get("VO_ORACLE_LIB") or os.path.join(_HERE, "libvo_oracle.so")   # VO_ORACLE_LIB: the sanitizer build (make asan)
 _SRC = ["src/sgbm.c", "src/imgproc.c", "src/orb.c", "src/match.c", "src/geom.c", "src/ransac.c", "src/fivept.c", "src/pnp.c", "vo_oracle.h"]
 
 
 def build_oracle(force=False):
     newest = max(os.path.getmtime(os.path.join(_HERE, s)) for s in _SRC)
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < newest:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libvo_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_LIB)], stdout=subprocess.DEVNULL)
     return _LIB
 
 
