@@ -1148,10 +1148,7 @@ static int launch_diag(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int16
         if (ctx->tune_diag_nwc == 15)
             return pad ? launch_diag_k<NP, true, 15, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 15, REV, WTA>(ctx, g, in1, sout, ctl);
     }
-#ifdef VO_DIAG_NWC3
-    if (ctx->tune_diag_nwc == 3)
-        return pad ? launch_diag_k<NP, true, 3, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 3, REV, WTA>(ctx, g, in1, sout, ctl);
-#endif
+
     return pad ? launch_diag_k<NP, true, 7, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 7, REV, WTA>(ctx, g, in1, sout, ctl);
 }
 
