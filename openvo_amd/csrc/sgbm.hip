@@ -1126,7 +1126,7 @@ static int launch_diag_k(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int
     if (j.tag == 0) j.tag = ++ctx->sw_tag;
     j.sink = ctx->max_w * ctx->max_h;          // every pixel array is allocated with 256 spare bytes
     j.dbg = ctx->tune_diag_dbg;
-    const size_t lds = (size_t)2 * 2 * CW * g.Dp * 2 + (WTA ? (size_t)NWC * 4 * 2 * g.Dp * 2 : 0) + 64;
+    const size_t lds = (size_t)DG_RING * 2 * CW * g.Dp * 2 + (WTA ? (size_t)NWC * 4 * 2 * g.Dp * 2 : 0) + 64 * 4;
     auto kern = k_sgbm_diag<NP, PAD, NWC, REV, WTA>;
     static unsigned long long attr_set = 0;     // per instantiation and device: allow more than 64 KB of dynamic LDS
     if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
