@@ -220,6 +220,20 @@ int vo_upload_mono(vo_ctx* ctx, int slot, const uint8_t* img, int w, int h, int 
 int vo_prefetch_staged_mono(vo_ctx* ctx, int slot, int index, int nfeatures);
 int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4, int iters, float thr, uint32_t seed,
                  int solver, double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx, int cap);
+/* The same step in two halves, so that several pairs can be in flight (a monocular stream is latency-bound otherwise: each
+ * pair's chain is short and narrow).  _begin enqueues the chain on one of VO_NUM_MONO_ASYNC alternates (own stream, scratch
+ * and pinned result record), ordered behind whatever still produces the two slots, and returns a ticket; _end waits for that
+ * ticket's completion event only and copies the record out.  want_matches != 0: mask / q / t and the second slot's keypoint
+ * positions (xy_b_out: `cap` x 2 floats, may be NULL) travel with the record.  Results are those of vo_mono_pair, bit for bit.
+ * A slot read by an open ticket may be refilled at any time: the refill is ordered behind the ticket's work on the device.
+ * VO_E_STATE when every alternate is open. */
+#define VO_NUM_MONO_ASYNC 3
+/* 1 when the look-ahead work into `slot` (vo_prefetch_*) has finished or none is pending, 0 while it still runs; never blocks */
+int vo_slot_ready(vo_ctx* ctx, int slot, int* ready_out);
+int vo_mono_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4, int iters, float thr, uint32_t seed,
+                       int solver, int want_matches, int* ticket_out);
+int vo_mono_pair_end(vo_ctx* ctx, int ticket, double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx,
+                     float* xy_b_out, int cap);
 
 /* RANSAC solvePnP hypothesis scoring (north star; BASELINE config 2 names "ORB+SGBM+PnP") ----------
  * NOT part of the reference either (openVO fits 3-D/3-D, stereo_odometer.py:187-205): defined by this

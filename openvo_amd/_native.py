@@ -15,6 +15,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 
 VO_NUM_SLOTS = 28
 VO_NUM_HOST_STAGE = 16
+VO_NUM_MONO_ASYNC = 3
 SCHED_DIAG, SCHED_DIAG_RAGGED, SCHED_UNFUSED = 1, 2, 3
 T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose")
 
@@ -30,7 +31,7 @@ SYMBOLS = [
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_essential5", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
     "vo_sgbm_last_geometry", "vo_host_stage_pair", "vo_host_stage_fetch", "vo_prefetch_host_staged", "vo_lookahead_depth", "vo_lookahead_drop", "vo_sgbm_last_schedule", "vo_measure_copy", "vo_sgbm_sweep_status", "vo_sgbm_sweep_stats",
-    "vo_upload_mono", "vo_prefetch_staged_mono", "vo_mono_pair",
+    "vo_upload_mono", "vo_prefetch_staged_mono", "vo_mono_pair", "vo_mono_pair_begin", "vo_mono_pair_end", "vo_slot_ready",
     "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_info", "vo_mgpu_last_error",
     "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
 ]
@@ -128,6 +129,9 @@ def lib():
         L.vo_upload_mono.argtypes = [vp, ci, vp, ci, ci, ci]
         L.vo_prefetch_staged_mono.argtypes = [vp, ci, ci, ci]
         L.vo_mono_pair.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, ci, vp, vp, vp, vp, vp, ci]
+        L.vo_slot_ready.argtypes = [vp, ci, vp]
+        L.vo_mono_pair_begin.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, ci, ci, vp]
+        L.vo_mono_pair_end.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci]
         L.vo_device_count.argtypes = [vp]
         L.vo_mgpu_unique_id.argtypes = [vp]
         L.vo_mgpu_create.argtypes = [ci, ci, ci, vp, vp]
@@ -515,6 +519,37 @@ class Context:
         if want_matches:
             m = int(c3[0])
             out.update(mask=mask[:m].copy(), q=q[:m].copy(), t=t[:m].copy())
+        return out
+
+    def slot_ready(self, slot):
+        r = ctypes.c_int(0)
+        self._ck(self._lib.vo_slot_ready(self._h, int(slot), ctypes.byref(r)))
+        return bool(r.value)
+
+    def mono_pair_begin(self, slot_a, slot_b, ratio, K4, iters=5000, thr=1.0, seed=4321, want_matches=False, solver=8):
+        """mono_pair in two halves (several pairs in flight): -> ticket for mono_pair_end."""
+        K4 = _c(np.asarray(K4, np.float64).reshape(4), np.float64)
+        t = ctypes.c_int(-1)
+        self._ck(self._lib.vo_mono_pair_begin(self._h, int(slot_a), int(slot_b), float(ratio), _p(K4), int(iters), float(thr),
+                                              int(seed) & 0xFFFFFFFF, int(solver), int(bool(want_matches)), ctypes.byref(t)))
+        return t.value
+
+    def mono_pair_end(self, ticket, want_matches=False):
+        """-> the dict mono_pair returns (+ "xy_b": keypoint positions of the second slot, when want_matches)."""
+        E = np.zeros(9, np.float64)
+        c3 = np.zeros(3, np.int32)
+        cap = self.kp_cap
+        mask = np.empty(cap, np.uint8) if want_matches else None
+        q = np.empty(cap, np.int32) if want_matches else None
+        t = np.empty(cap, np.int32) if want_matches else None
+        xy = np.empty((cap, 2), np.float32) if want_matches else None
+        self._ck(self._lib.vo_mono_pair_end(self._h, int(ticket), _p(E), _p(c3), _p(mask) if want_matches else None,
+                                            _p(q) if want_matches else None, _p(t) if want_matches else None,
+                                            _p(xy) if want_matches else None, cap))
+        out = {"E": E.reshape(3, 3), "matches": int(c3[0]), "best_iter": int(c3[1]), "best_count": int(c3[2])}
+        if want_matches:
+            m = int(c3[0])
+            out.update(mask=mask[:m].copy(), q=q[:m].copy(), t=t[:m].copy(), xy_b=xy)
         return out
 
     def ransac_pnp(self, pts3d, pts2d, K4, iters=5000, thr=2.0, seed=4321, want_counts=False):

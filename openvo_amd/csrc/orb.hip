@@ -121,6 +121,8 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h)
         if (ctx->la_stream[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream[k]));
     for (int k = 0; k < vo_ctx::N_POSE_ALT; k++)
         if (ctx->pose_alt[k].stream) VO_HIP(ctx, hipStreamSynchronize(ctx->pose_alt[k].stream));
+    for (int k = 0; k < vo_ctx::N_MONO_ALT; k++)
+        if (ctx->mono_alt[k].stream) VO_HIP(ctx, hipStreamSynchronize(ctx->mono_alt[k].stream));
     VO_HIP(ctx, hipMemcpyAsync(ctx->rs_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     VO_HIP(ctx, hipMemcpyAsync(ctx->rs_coef, coef.data(), coef.size() * 2, hipMemcpyHostToDevice, ctx->stream));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -319,25 +319,15 @@ __global__ void k_ransac_pick(const double* __restrict__ E_all, const int32_t* _
 
 // Monocular pair step (BASELINE config 5; no reference counterpart): the keypoints and descriptors two slots
 // already hold -> brute-force Hamming kNN-2 -> ratio test + ordered compaction -> essential-matrix RANSAC on the
-// surviving correspondences, every stage on the device, ONE host synchronisation at the end.
-extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4v, int iters, float thr, uint32_t seed,
-                            int solver, double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx, int cap)
+// surviving correspondences, every stage on the device.  mono_enqueue puts the whole chain on ctx->stream with the
+// context's CURRENT match scratch (m_idx .. xy_b, m_count) and RANSAC workspace -- the main ones (vo_mono_pair: one
+// host synchronisation at the end) or those of an asynchronous alternate (vo_mono_pair_begin / _end).
+struct MonoDev { int32_t* d_best; double* d_E9; uint8_t* d_mask; };
+
+static int mono_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, const double* K4v, int iters, float thr, uint32_t seed,
+                        int solver, MonoDev& o)
 {
-    if (solver != 5 && solver != 8) return vo_fail(ctx, VO_E_ARG, "vo_mono_pair: solver is 5 (five-point) or 8 (eight-point)");
     const int min_n = solver == 5 ? 6 : 8;
-    if (!ctx || slot_a < 0 || slot_a >= VO_NUM_SLOTS || slot_b < 0 || slot_b >= VO_NUM_SLOTS || !K4v || !E9_out || !counts3)
-        return vo_fail(ctx, VO_E_ARG, "vo_mono_pair: bad argument");
-    if (iters <= 0 || iters > (1 << 22)) return vo_fail(ctx, VO_E_ARG, "vo_mono_pair: need 0 < iters <= 4194304");
-    FrameSlot& a = ctx->slots[slot_a];
-    FrameSlot& b = ctx->slots[slot_b];
-    if (!a.has_kp || !b.has_kp) return vo_fail(ctx, VO_E_STATE, "vo_mono_pair: both slots need keypoints (vo_orb_detect_and_compute)");
-    counts3[0] = counts3[1] = counts3[2] = 0;
-    for (int k = 0; k < 9; k++) E9_out[k] = 0.0;
-    if (a.n_kp == 0) return VO_OK;
-    if (b.n_kp < 2) return vo_fail(ctx, VO_E_ARG, "train set has fewer than 2 descriptors");
-    if ((mask_out || q_idx || t_idx) && cap < a.n_kp) return vo_fail(ctx, VO_E_CAP, "vo_mono_pair: outputs hold %d entries, %d keypoints", cap, a.n_kp);
-    VO_HIP(ctx, hipSetDevice(ctx->device));
-    { int rcw = slot_wait(ctx, a); if (!rcw) rcw = slot_wait(ctx, b); if (rcw) return rcw; }
     const int nq = a.n_kp;
     const size_t need = (size_t)iters * (72 + 36 + 4) + (size_t)nq + 4096;
     if (ctx->ransac_ws_bytes < need) {
@@ -351,9 +341,9 @@ extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, c
     double* d_E = (double*)w; w += (size_t)iters * 72;
     float* d_F = (float*)w; w += (size_t)iters * 36;
     int32_t* d_counts = (int32_t*)w; w += (size_t)iters * 4;
-    int32_t* d_best = (int32_t*)w; w += 256;
-    double* d_E9 = (double*)w; w += 256;
-    uint8_t* d_mask = w;
+    o.d_best = (int32_t*)w; w += 256;
+    o.d_E9 = (double*)w; w += 256;
+    o.d_mask = w;
     int rc;
     {
         StageTimer t(ctx, VO_T_MATCH);
@@ -372,21 +362,193 @@ extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, c
         else
             hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, K, iters, seed, d_E, d_F, ctx->m_count);
         hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, iters, thr2, d_counts, ctx->m_count, min_n);
-        hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(1024), 0, ctx->stream, d_counts, iters, d_best);
-        hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, d_best, thr2, d_mask, ctx->m_count, min_n);
-        hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, ctx->stream, d_E, d_best, d_E9);
+        hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(1024), 0, ctx->stream, d_counts, iters, o.d_best);
+        hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, o.d_best, thr2, o.d_mask, ctx->m_count, min_n);
+        hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, ctx->stream, d_E, o.d_best, o.d_E9);
         VO_CHECK_LAUNCH(ctx);
     }
+    return VO_OK;
+}
+
+static int mono_check(vo_ctx* ctx, int slot_a, int slot_b, const double* K4v, int iters, int solver, const char* who)
+{
+    if (solver != 5 && solver != 8) return vo_fail(ctx, VO_E_ARG, "%s: solver is 5 (five-point) or 8 (eight-point)", who);
+    if (!ctx || slot_a < 0 || slot_a >= VO_NUM_SLOTS || slot_b < 0 || slot_b >= VO_NUM_SLOTS || !K4v)
+        return vo_fail(ctx, VO_E_ARG, "%s: bad argument", who);
+    if (iters <= 0 || iters > (1 << 22)) return vo_fail(ctx, VO_E_ARG, "%s: need 0 < iters <= 4194304", who);
+    FrameSlot& a = ctx->slots[slot_a];
+    FrameSlot& b = ctx->slots[slot_b];
+    if (!a.has_kp || !b.has_kp) return vo_fail(ctx, VO_E_STATE, "%s: both slots need keypoints (vo_orb_detect_and_compute)", who);
+    if (a.n_kp > 0 && b.n_kp < 2) return vo_fail(ctx, VO_E_ARG, "train set has fewer than 2 descriptors");
+    return VO_OK;
+}
+
+extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4v, int iters, float thr, uint32_t seed,
+                            int solver, double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx, int cap)
+{
+    if (ctx && (!E9_out || !counts3)) return vo_fail(ctx, VO_E_ARG, "vo_mono_pair: bad argument");
+    int rc = mono_check(ctx, slot_a, slot_b, K4v, iters, solver, "vo_mono_pair");
+    if (rc) return rc;
+    const int min_n = solver == 5 ? 6 : 8;
+    FrameSlot& a = ctx->slots[slot_a];
+    FrameSlot& b = ctx->slots[slot_b];
+    counts3[0] = counts3[1] = counts3[2] = 0;
+    for (int k = 0; k < 9; k++) E9_out[k] = 0.0;
+    if (a.n_kp == 0) return VO_OK;
+    if ((mask_out || q_idx || t_idx) && cap < a.n_kp) return vo_fail(ctx, VO_E_CAP, "vo_mono_pair: outputs hold %d entries, %d keypoints", cap, a.n_kp);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    { int rcw = slot_wait(ctx, a); if (!rcw) rcw = slot_wait(ctx, b); if (rcw) return rcw; }
+    const int nq = a.n_kp;
+    MonoDev o;
+    if ((rc = mono_enqueue(ctx, a, b, ratio, K4v, iters, thr, seed, solver, o))) return rc;
     int32_t* h = (int32_t*)ctx->pinned;         // [0] M, [1..2] best, then E9 at byte 64
     VO_HIP(ctx, hipMemcpyAsync(h, ctx->m_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipMemcpyAsync(h + 1, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(ctx, hipMemcpyAsync((uint8_t*)ctx->pinned + 64, d_E9, 72, hipMemcpyDeviceToHost, ctx->stream));
-    if (mask_out && (rc = xfer_d2h(ctx, mask_out, d_mask, (size_t)nq))) return rc;
+    VO_HIP(ctx, hipMemcpyAsync(h + 1, o.d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync((uint8_t*)ctx->pinned + 64, o.d_E9, 72, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask_out && (rc = xfer_d2h(ctx, mask_out, o.d_mask, (size_t)nq))) return rc;
     if (q_idx && (rc = xfer_d2h(ctx, q_idx, ctx->mq_idx, (size_t)nq * 4))) return rc;
     if (t_idx && (rc = xfer_d2h(ctx, t_idx, ctx->mt_idx, (size_t)nq * 4))) return rc;
     if ((rc = xfer_flush(ctx))) return rc;       // the one synchronisation
     counts3[0] = h[0]; counts3[1] = h[1]; counts3[2] = h[0] >= min_n ? h[2] : 0;
     memcpy(E9_out, (uint8_t*)ctx->pinned + 64, 72);
+    return VO_OK;
+}
+
+// ---- the same step, asynchronous: several pairs' chains in flight (each on an alternate's own stream and scratch) ----------
+// A monocular stream is latency-bound when every pair is enqueued, waited for and only then followed by the next one (the
+// five-point kernel alone runs 0.26 ms on 79 of the 1024 SIMDs).  Consecutive pairs do not depend on each other's result --
+// only on the caller's decision which frame is the reference -- so a caller that knows the next frame may begin its pair
+// before it collects this one's.  Results land in the alternate's pinned record; vo_mono_pair_end waits for its event only.
+static const size_t MONO_HDR = 4096;             // record: [0] M, [1..2] best, E9 at byte 64; arrays from MONO_HDR on
+
+static void mono_swap(vo_ctx* ctx, int k)
+{
+    vo_ctx::MonoAlt& p = ctx->mono_alt[k];
+    std::swap(ctx->stream, p.stream);
+    std::swap(ctx->m_idx, p.m_idx); std::swap(ctx->m_count, p.m_count); std::swap(ctx->m_dist, p.m_dist);
+    std::swap(ctx->mq_idx, p.mq_idx); std::swap(ctx->mt_idx, p.mt_idx);
+    std::swap(ctx->xy_a, p.xy_a); std::swap(ctx->xy_b, p.xy_b);
+    std::swap(ctx->ransac_ws, p.ransac_ws); std::swap(ctx->ransac_ws_bytes, p.ransac_ws_bytes);
+}
+
+static void mono_alt_release(vo_ctx::MonoAlt& p)
+{
+    if (p.stream) (void)hipStreamSynchronize(p.stream);
+    void* ps[] = { p.m_idx, p.m_dist, p.m_count, p.mq_idx, p.mt_idx, p.xy_a, p.xy_b, p.ransac_ws };
+    for (void* q : ps) if (q) (void)hipFree(q);
+    if (p.result) (void)hipHostFree(p.result);
+    if (p.done) (void)hipEventDestroy(p.done);
+    if (p.stream) (void)hipStreamDestroy(p.stream);
+    p = vo_ctx::MonoAlt();
+}
+
+static int mono_alt_prepare(vo_ctx* ctx, int k)
+{
+    vo_ctx::MonoAlt& p = ctx->mono_alt[k];
+    if (p.ready) return VO_OK;
+    const size_t cap = (size_t)ctx->kp_cap;
+    hipError_t e = hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p.done, hipEventDisableTiming);
+    p.result_bytes = MONO_HDR + cap * (1 + 4 + 4 + 8) + 64;
+    if (e == hipSuccess) e = hipHostMalloc((void**)&p.result, p.result_bytes, hipHostMallocDefault);
+    void** ps[] = { (void**)&p.m_idx, (void**)&p.m_dist, (void**)&p.m_count, (void**)&p.mq_idx, (void**)&p.mt_idx, (void**)&p.xy_a, (void**)&p.xy_b };
+    const size_t sz[] = { cap * 8, cap * 8, 256, cap * 4, cap * 4, cap * 8, cap * 8 };
+    for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]) && e == hipSuccess; i++) e = hipMalloc(ps[i], sz[i] + 256);
+    if (e != hipSuccess) {
+        mono_alt_release(p);                      // a partly built alternate is given back whole
+        return vo_fail(ctx, VO_E_HIP, "asynchronous monocular step: allocation failed: %s", hipGetErrorString(e));
+    }
+    p.ready = true;
+    return VO_OK;
+}
+
+void mono_alt_free(vo_ctx* ctx)
+{
+    for (int k = 0; k < vo_ctx::N_MONO_ALT; k++) mono_alt_release(ctx->mono_alt[k]);
+}
+
+extern "C" int vo_mono_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4v, int iters, float thr, uint32_t seed,
+                                  int solver, int want_matches, int* ticket_out)
+{
+    if (ctx && !ticket_out) return vo_fail(ctx, VO_E_ARG, "vo_mono_pair_begin: bad argument");
+    int rc = mono_check(ctx, slot_a, slot_b, K4v, iters, solver, "vo_mono_pair_begin");
+    if (rc) return rc;
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    int k = -1;                                   // the first free alternate from the round-robin position on (tickets need not end in order)
+    for (int i = 0; i < vo_ctx::N_MONO_ALT && k < 0; i++)
+        if (!ctx->mono_alt[(ctx->mono_next + i) % vo_ctx::N_MONO_ALT].busy) k = (ctx->mono_next + i) % vo_ctx::N_MONO_ALT;
+    if (k < 0) return vo_fail(ctx, VO_E_STATE, "vo_mono_pair_begin: every asynchronous step is still open (end one first)");
+    vo_ctx::MonoAlt& p = ctx->mono_alt[k];
+    if ((rc = mono_alt_prepare(ctx, k))) return rc;
+    FrameSlot& a = ctx->slots[slot_a];
+    FrameSlot& b = ctx->slots[slot_b];
+    memset(p.result, 0, MONO_HDR);
+    p.nq = a.n_kp; p.nb = b.n_kp; p.min_n = solver == 5 ? 6 : 8; p.want = want_matches != 0;
+    // the step runs on the alternate's own stream: behind whatever still produces the two slots (look-ahead engines) and
+    // behind the main stream's work on them
+    VO_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    {
+        struct MonoScope {      // the context works on alternate k's stream and scratch inside this block, whatever leaves it
+            vo_ctx* c; int k;
+            MonoScope(vo_ctx* c_, int k_) : c(c_), k(k_) { mono_swap(c, k); }
+            ~MonoScope() { mono_swap(c, k); }
+        } on_alt(ctx, k);
+        hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev0, 0);
+        if (e == hipSuccess && a.pending) e = hipStreamWaitEvent(ctx->stream, a.ready, 0);
+        if (e == hipSuccess && b.pending) e = hipStreamWaitEvent(ctx->stream, b.ready, 0);
+        rc = e == hipSuccess ? VO_OK : vo_fail(ctx, VO_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+        if (!rc && a.n_kp > 0) {
+            MonoDev o;
+            rc = mono_enqueue(ctx, a, b, ratio, K4v, iters, thr, seed, solver, o);
+            uint8_t* r = p.result;
+            const size_t nq = (size_t)a.n_kp, nb = (size_t)b.n_kp;
+            if (!rc) e = hipMemcpyAsync(r, ctx->m_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (!rc && e == hipSuccess) e = hipMemcpyAsync(r + 4, o.d_best, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (!rc && e == hipSuccess) e = hipMemcpyAsync(r + 64, o.d_E9, 72, hipMemcpyDeviceToHost, ctx->stream);
+            if (!rc && p.want) {
+                uint8_t* q = r + MONO_HDR;
+                const size_t cap = (size_t)ctx->kp_cap;
+                if (e == hipSuccess) e = hipMemcpyAsync(q, o.d_mask, nq, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(q + cap, ctx->mq_idx, nq * 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(q + cap * 5, ctx->mt_idx, nq * 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess && nb) e = hipMemcpyAsync(q + cap * 9, b.kp_xy, nb * 8, hipMemcpyDeviceToHost, ctx->stream);
+            }
+            if (!rc && e != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+        }
+        if (!rc && hipEventRecord(p.done, ctx->stream) != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
+    }
+    if (rc) return rc;
+    // both slots are read on this alternate's stream until p.done: whoever refills one of them waits for it first
+    for (FrameSlot* f : { &a, &b }) {
+        if (f->readers[0] == p.done || f->readers[1] == p.done) continue;
+        f->readers[f->readers[0] ? 1 : 0] = p.done;
+    }
+    p.busy = true;
+    ctx->mono_next = (k + 1) % vo_ctx::N_MONO_ALT;
+    *ticket_out = k;
+    return VO_OK;
+}
+
+extern "C" int vo_mono_pair_end(vo_ctx* ctx, int ticket, double* E9_out, int32_t* counts3, uint8_t* mask_out, int32_t* q_idx, int32_t* t_idx,
+                                float* xy_b_out, int cap)
+{
+    if (!ctx || ticket < 0 || ticket >= vo_ctx::N_MONO_ALT || !E9_out || !counts3) return vo_fail(ctx, VO_E_ARG, "vo_mono_pair_end: bad argument");
+    vo_ctx::MonoAlt& p = ctx->mono_alt[ticket];
+    if (!p.busy) return vo_fail(ctx, VO_E_STATE, "vo_mono_pair_end: ticket %d is not open", ticket);
+    if ((mask_out || q_idx || t_idx) && (!p.want || cap < p.nq)) return vo_fail(ctx, VO_E_CAP, "vo_mono_pair_end: outputs hold %d entries, %d keypoints (or the step was begun without want_matches)", cap, p.nq);
+    if (xy_b_out && (!p.want || cap < p.nb)) return vo_fail(ctx, VO_E_CAP, "vo_mono_pair_end: xy_b_out holds %d entries, %d keypoints", cap, p.nb);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    p.busy = false;
+    VO_HIP(ctx, hipEventSynchronize(p.done));
+    const int32_t* h = (const int32_t*)p.result;
+    counts3[0] = h[0]; counts3[1] = h[1]; counts3[2] = h[0] >= p.min_n ? h[2] : 0;
+    memcpy(E9_out, p.result + 64, 72);
+    const uint8_t* q = p.result + MONO_HDR;
+    const size_t kc = (size_t)ctx->kp_cap;
+    if (mask_out) memcpy(mask_out, q, (size_t)p.nq);
+    if (q_idx) memcpy(q_idx, q + kc, (size_t)p.nq * 4);
+    if (t_idx) memcpy(t_idx, q + kc * 5, (size_t)p.nq * 4);
+    if (xy_b_out) memcpy(xy_b_out, q + kc * 9, (size_t)p.nb * 8);
     return VO_OK;
 }
 

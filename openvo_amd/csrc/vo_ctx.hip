@@ -232,6 +232,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     for (void* p : ps) if (p) (void)hipFree(p);
     orb_ws_free(ctx->orb);
     pose_alt_free(ctx);
+    mono_alt_free(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->slot_words) (void)hipHostFree(ctx->slot_words);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -269,6 +270,10 @@ extern "C" int vo_synchronize(vo_ctx* ctx)
     if (!ctx) return VO_E_ARG;
     for (int k = 0; k < vo_ctx::MAX_ENGINES; k++)
         if (ctx->la_stream[k]) VO_HIP(ctx, hipStreamSynchronize(ctx->la_stream[k]));
+    for (int k = 0; k < vo_ctx::N_POSE_ALT; k++)
+        if (ctx->pose_alt[k].stream) VO_HIP(ctx, hipStreamSynchronize(ctx->pose_alt[k].stream));
+    for (int k = 0; k < vo_ctx::N_MONO_ALT; k++)
+        if (ctx->mono_alt[k].stream) VO_HIP(ctx, hipStreamSynchronize(ctx->mono_alt[k].stream));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }
@@ -1048,6 +1053,20 @@ extern "C" int vo_lookahead_depth(vo_ctx* ctx, int* depth_out)
 {
     if (!ctx || !depth_out) return VO_E_ARG;
     *depth_out = ctx->inflight;
+    return VO_OK;
+}
+
+// has the look-ahead work into this slot finished?  (never blocks: a caller that runs ahead speculatively only picks up what is there)
+extern "C" int vo_slot_ready(vo_ctx* ctx, int slot, int* ready_out)
+{
+    if (!ctx || slot < 0 || slot >= VO_NUM_SLOTS || !ready_out) return vo_fail(ctx, VO_E_ARG, "vo_slot_ready: bad argument");
+    FrameSlot& f = ctx->slots[slot];
+    *ready_out = 1;
+    if (f.pending) {
+        const hipError_t e = hipEventQuery(f.ready);
+        if (e == hipErrorNotReady) *ready_out = 0;
+        else if (e != hipSuccess) return vo_fail(ctx, VO_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+    }
     return VO_OK;
 }
 

@@ -190,6 +190,21 @@ struct vo_ctx {
         size_t clique_ws_bytes = 0;
     } pose_alt[N_POSE_ALT];
     int pose_next = 0;
+    // asynchronous monocular pair steps (vo_mono_pair_begin / _end): match scratch + RANSAC workspace + stream + pinned record each
+    static const int N_MONO_ALT = 3;
+    struct MonoAlt {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        uint8_t* result = nullptr;     // pinned: header (M, best, E) + mask / q / t / xy of the second frame
+        size_t result_bytes = 0;
+        bool ready = false, busy = false, want = false;
+        int nq = 0, nb = 0, min_n = 0;
+        int32_t *m_idx = nullptr, *m_count = nullptr, *m_dist = nullptr, *mq_idx = nullptr, *mt_idx = nullptr;
+        float *xy_a = nullptr, *xy_b = nullptr;
+        uint8_t* ransac_ws = nullptr;
+        size_t ransac_ws_bytes = 0;
+    } mono_alt[N_MONO_ALT];
+    int mono_next = 0;
     uint8_t* ransac_ws = nullptr;
     size_t ransac_ws_bytes = 0;
     float* img3_ws = nullptr;
@@ -263,6 +278,7 @@ int slot_wait(vo_ctx* ctx, FrameSlot& f);
 int slot_before_overwrite(vo_ctx* ctx, FrameSlot& f);
 int orb_slot_enqueue(vo_ctx* ctx, FrameSlot& f, int nfeatures, int mask_mode, int min_disp16, int max_disp16);
 void pose_alt_free(vo_ctx* ctx);
+void mono_alt_free(vo_ctx* ctx);
 size_t pose_ws_bytes(int nq);
 __global__ void k_ratio_compact(const int32_t* idx, const int32_t* dist, int nq, double ratio, const float* xy_q, const float* xy_t,
                                 int32_t* q_out, int32_t* t_out, float* xyq_out, float* xyt_out, int32_t* m_out);   // pose / clique scratch for nq query keypoints

@@ -74,20 +74,50 @@ class MonoOdometer:
         self.skip_cause = ""
         # staged streams run ahead: the ORB extraction of the next frames is enqueued on look-ahead engines
         # (vo_prefetch_staged_mono) while the main stream matches and scores the current pair
-        self.lookahead = int(os.environ.get("VO_MONO_LOOKAHEAD", "3"))
-        self._free = list(range(8))      # frame slots this odometer uses
+        self.lookahead = int(os.environ.get("VO_MONO_LOOKAHEAD", "4"))
+        # ... and so do the pair steps: frame k + 1's step against frame k is begun (vo_mono_pair_begin, own stream) before
+        # frame k's own step has been collected, on the assumption that k will be accepted as the next reference.  The
+        # chains of up to `speculate` later pairs overlap the current one's; a rejected frame voids them (they are collected
+        # and dropped, the pair is run again against the reference that stayed).  Results do not depend on any of this.
+        self.speculate = max(0, min(int(os.environ.get("VO_MONO_SPECULATE", "2")), _native.VO_NUM_MONO_ASYNC - 1))
+        self._free = list(range(10))     # frame slots this odometer uses
         self._ahead = {}                 # staged index -> slot with its extraction in flight
+        self._count = {}                 # slot -> keypoint count, once the host has collected it
+        self._open = {}                  # (slot_a, slot_b) -> ticket of a step begun and not yet collected
         self._ref = None                 # (slot, xy) of the reference frame
         self._n_staged = 0
+        self.speculation = {"begun": 0, "used": 0, "void": 0}
+
+    def _void_open(self):
+        """Collect and drop every begun step (their premise -- which frame is the reference -- fell)."""
+        for key in list(self._open):
+            self._ctx.mono_pair_end(self._open.pop(key), want_matches=True)
+            self.speculation["void"] += 1
+
+    def reset_lookahead(self):
+        """Forget everything begun ahead (extractions and pair steps of frames not asked for yet): the next update starts from
+        the reference frame alone.  For measurements: nothing computed before the clock starts is used after it."""
+        self._drop_ahead()
+
+    def _drop_ahead(self):
+        self._void_open()
+        for s in self._ahead.values():                            # the predictions are void (their extractions may still run:
+            self._ctx.lookahead_drop(s)                           # the native side orders the slot's next use behind them)
+            self._count.pop(s, None)
+            self._free.append(s)
+        self._ahead = {}
 
     def stage_frames(self, frames):
         """Keep a list of images resident in HBM; update(k) with an int then reads frame k from there."""
+        self._drop_ahead()
         self._ctx.stage_pairs([(f, f) for f in frames])
         self._n_staged = len(frames)
-        for s in self._ahead.values():
-            self._ctx.lookahead_drop(s)
-            self._free.append(s)
-        self._ahead = {}
+
+    def _begin(self, a, b):
+        t = self._ctx.mono_pair_begin(a, b, self.match_threshold, self.K4, self.ransac_iters, self.ransac_threshold, self.seed,
+                                      want_matches=True, solver=self.solver)
+        self._open[(a, b)] = t
+        return t
 
     def update(self, img, scale=1.0):
         """One frame (an image, or the index of a staged one); True when a relative pose was accepted (always True
@@ -97,11 +127,9 @@ class MonoOdometer:
         if staged and int(img) in self._ahead:
             cur = self._ahead.pop(int(img))                       # extraction already running on an engine
         else:
-            for s in self._ahead.values():                        # out-of-order request: the predictions are void (their
-                ctx.lookahead_drop(s)                             # extractions may still run: the native side orders the
-                self._free.append(s)                              # slot's next use behind them)
-            self._ahead = {}
+            self._drop_ahead()                                    # out-of-order request
             cur = self._free.pop()
+            self._count.pop(cur, None)
             if staged:
                 ctx.load_staged_pair(cur, int(img), True)
             else:
@@ -110,26 +138,65 @@ class MonoOdometer:
             for j in range(int(img) + 1, min(int(img) + 1 + self.lookahead, self._n_staged)):
                 if j not in self._ahead and len(self._free) > 1:
                     nxt = self._free.pop()
+                    self._count.pop(nxt, None)
                     ctx.prefetch_staged_mono(nxt, j, self.nfeatures)
                     self._ahead[j] = nxt
-        n = ctx.orb_slot_count(cur, self.nfeatures, 0)
+        n = self._count.pop(cur, None)
+        if n is None:
+            n = ctx.orb_slot_count(cur, self.nfeatures, 0)
         if n < 8:
             self.skip_cause = "keypoints"
+            self._void_open()
             self._free.append(cur)
             return False
         if self._ref is None:
+            self._void_open()
             self._ref = (cur, ctx.download_keypoints_xy(cur).astype(np.float64))
             return True
         prev, xy_prev = self._ref
-        r = ctx.mono_pair(prev, cur, self.match_threshold, self.K4, self.ransac_iters, self.ransac_threshold, self.seed, want_matches=True, solver=self.solver)
+        key = (prev, cur)
+        # steps begun ahead stand as long as they lie on the chain reference -> this frame -> the frames predicted next
+        chain, a = {key}, cur
+        if staged:
+            for j in range(int(img) + 1, int(img) + 1 + self.speculate):
+                if j not in self._ahead:
+                    break
+                chain.add((a, self._ahead[j]))
+                a = self._ahead[j]
+        for k2 in [k2 for k2 in self._open if k2 not in chain]:
+            ctx.mono_pair_end(self._open.pop(k2), want_matches=True)
+            self.speculation["void"] += 1
+        if key in self._open:
+            self.speculation["used"] += 1
+        else:
+            self._begin(prev, cur)
+        # the later pairs, on the assumption that every frame up to them is accepted: only what is already extracted (no wait)
+        if staged and self.speculate:
+            a, na = cur, n
+            for j in range(int(img) + 1, int(img) + 1 + self.speculate):
+                b = self._ahead.get(j)
+                if b is None or len(self._open) > self.speculate:
+                    break
+                if b not in self._count:
+                    if not ctx.slot_ready(b):
+                        break
+                    self._count[b] = ctx.orb_slot_count(b, self.nfeatures, 0)
+                if na < 8 or self._count[b] < 8:
+                    break
+                if (a, b) not in self._open:
+                    self._begin(a, b)
+                    self.speculation["begun"] += 1
+                a, na = b, self._count[b]
+        r = ctx.mono_pair_end(self._open.pop(key), want_matches=True)
         self.last = r
         need = 6 if self.solver == 5 else 8
         if r["matches"] < need or r["best_count"] < self.min_inliers:
             self.skip_cause = "matches" if r["matches"] < need else "inliers"
+            self._void_open()            # the steps begun ahead took this frame for the next reference
             self._free.append(cur)
             return False                 # the previous frame stays the reference
         inl = np.nonzero(r["mask"])[0][:512]                      # a few hundred inliers decide the cheirality vote
-        xy_cur = ctx.download_keypoints_xy(cur).astype(np.float64)
+        xy_cur = r["xy_b"][:n].astype(np.float64)
         xa, xb = xy_prev[r["q"][inl]], xy_cur[r["t"][inl]]
         fx, fy, cx, cy = self.K4
         # E -> (R, t) is host arithmetic on a few hundred inliers: it runs on a worker thread while this thread is inside
@@ -161,6 +228,7 @@ class MonoOdometer:
 
     def close(self):
         """Collect the pending pose, stop the worker thread and release the native context (if this object created it)."""
+        self._void_open()
         self._flush()
         self._pool.shutdown(wait=True)
         if self._own_ctx:

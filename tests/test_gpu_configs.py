@@ -311,6 +311,71 @@ def test_mono_lookahead_gives_the_same_chain():
     assert sum(x[0] for x in chains[3]) >= 6
 
 
+def test_mono_pair_begin_end_equals_the_synchronous_step_and_tickets_end_in_any_order():
+    """vo_mono_pair_begin / _end: three pairs in flight on three alternates give, bit for bit, what vo_mono_pair gives one at
+    a time; tickets may be collected in any order; a fourth begin is refused while all are open; a slot read by an open
+    ticket may be refilled (the refill is ordered behind the ticket on the device)."""
+    c = Corridor("C5")
+    K4 = [c.f, c.f, c.cx, c.cy]
+    ctx = _native.Context(0, c.w, c.h, 16, 3000)
+    frames = [c.pair(k)[0] for k in range(5)]
+    for s, f in enumerate(frames[:4]):
+        ctx.upload_mono(s, f)
+        assert ctx.orb_slot_count(s, 3000, 0) > 1000
+    want = [ctx.mono_pair(a, a + 1, 0.8, K4, 1500, 1.0, 4321, want_matches=True, solver=5) for a in range(3)]
+    xy = [ctx.download_keypoints_xy(s) for s in range(4)]
+    tickets = [ctx.mono_pair_begin(a, a + 1, 0.8, K4, 1500, 1.0, 4321, want_matches=True, solver=5) for a in range(3)]
+    assert sorted(tickets) == [0, 1, 2]
+    with pytest.raises(Exception):
+        ctx.mono_pair_begin(0, 1, 0.8, K4, 1500, 1.0, 4321, want_matches=True, solver=5)
+    ctx.upload_mono(0, frames[4])                                      # slot 0 is still being read by the first ticket
+    for a in (1, 2, 0):
+        got = ctx.mono_pair_end(tickets[a], want_matches=True)
+        w = want[a]
+        assert (got["matches"], got["best_iter"], got["best_count"]) == (w["matches"], w["best_iter"], w["best_count"]), a
+        assert np.array_equal(got["E"], w["E"]) and np.array_equal(got["mask"], w["mask"]), a
+        assert np.array_equal(got["q"], w["q"]) and np.array_equal(got["t"], w["t"]), a
+        assert np.array_equal(got["xy_b"][:len(xy[a + 1])], xy[a + 1]), a
+    with pytest.raises(Exception):
+        ctx.mono_pair_end(tickets[0], want_matches=True)               # not open any more
+    t = ctx.mono_pair_begin(1, 2, 0.8, K4, 1500, 1.0, 4321, want_matches=False, solver=8)   # alternates are free again
+    got = ctx.mono_pair_end(t)
+    ref = ctx.mono_pair(1, 2, 0.8, K4, 1500, 1.0, 4321, solver=8)
+    assert np.array_equal(got["E"], ref["E"]) and got["best_count"] == ref["best_count"]
+    ctx.close()
+
+
+def test_mono_speculative_pair_steps_survive_a_rejected_frame():
+    """MonoOdometer begins the steps of the next pairs before it has collected the current one's, assuming every frame will
+    be accepted.  A frame that is rejected (a blank image: no keypoints; an image of noise: too few matches / inliers) voids what
+    was begun ahead; flags, counts and poses equal the run without speculation, and both outcomes really occurred."""
+    from openvo_amd.mono import MonoOdometer
+    c = Corridor("C5")
+    K = np.array([[c.f, 0, c.cx], [0, c.f, c.cy], [0, 0, 1.0]])
+    frames = [c.pair(k)[0] for k in range(10)]
+    frames[3] = np.zeros_like(frames[3])                                # no keypoints
+    frames[6] = np.random.default_rng(5).integers(0, 256, frames[6].shape, dtype=np.uint8)   # noise: keypoints, but no consistent matches
+    chains, stats = {}, {}
+    for spec in (0, 2):
+        odo = MonoOdometer(K, (c.w, c.h), nfeatures=3000, ransac_iters=1500, min_inliers=200)
+        odo.speculate = spec
+        odo.stage_frames(frames)
+        chain = []
+        for k in range(len(frames)):
+            ok = odo.update(k)
+            chain.append((ok, odo.skip_cause if not ok else "", None if odo.last is None else (odo.last["matches"], odo.last["best_iter"], odo.last["best_count"]), odo.c_T_w.copy()))
+        chains[spec], stats[spec] = chain, dict(odo.speculation)
+        odo.close()
+    for (a, ca, la, Ta), (b, cb, lb, Tb) in zip(chains[0], chains[2]):
+        assert a == b and ca == cb and la == lb and np.array_equal(Ta, Tb)
+    flags = [x[0] for x in chains[2]]
+    assert flags[3] is False and chains[2][3][1] == "keypoints"
+    assert flags[6] is False and chains[2][6][1] in ("inliers", "matches")
+    assert sum(flags) >= 7
+    assert stats[0] == {"begun": 0, "used": 0, "void": 0}
+    assert stats[2]["used"] >= 3 and stats[2]["void"] >= 1, stats[2]
+
+
 def test_mono_unpredicted_request_while_predictions_are_in_flight():
     """update(0) starts the extraction of frames 1..3 on look-ahead engines; update(5) -- a frame nobody predicted -- voids
     them while they may still be running and immediately reuses one of their slots on another stream.  The slot's next use

@@ -457,7 +457,7 @@ def test_copy_ceiling_probe_is_sane_and_leaves_the_context_usable(oracle):
     before = cam.stereoSGBM.compute(L, R)
     for nt in (False, True):
         rate = cam._ctx.measure_copy(0, 5, nt)
-        assert 100.0 < rate < 16000.0, rate                      # GB/s, read + written; the HBM peak is 8000
+        assert 100.0 < rate < 40000.0, rate                      # GB/s, read + written (HBM peak 8000; a volume this small can sit in the 256 MB MALL)
     assert np.array_equal(cam.stereoSGBM.compute(L, R), before)
     with pytest.raises(Exception):
         cam._ctx.measure_copy(0, 0, False)                       # reps must be positive

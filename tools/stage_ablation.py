@@ -2,7 +2,8 @@
 
 Runs disparity only (no ORB, no pose) for N staged C2 pairs through the engines, once complete and once with each stage
 skipped (VO_DIAG_DEBUG bits: results are then garbage, only the clock counts); the time a stage adds under concurrency is
-the difference.  One process per variant (the knob is read at context creation)."""
+the difference.  One process per variant (the knob is read at context creation).
+Usage: python tools/stage_ablation.py [engine counts, e.g. 1,2,4,8,12]"""
 import os, subprocess, sys, time
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -25,10 +26,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print("%-28s %.3f ms/pair  (%.0f pairs/s)" % (os.environ.get("TAG", ""), 1e3 * dt / N, N / dt))
     sys.exit(0)
 
-for tag, env in (("default schedule", {"VO_DIAG": "0"}), ("diag: complete", {"VO_DIAG": "1"}), ("diag: no cost", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "4"}),
-                 ("diag: no W+E", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "8"}), ("diag: no diagonal", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "16"}),
-                 ("diag: no post", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "32"}), ("diag: only cost", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "56"}),
-                 ("diag: only W+E", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "52"}), ("diag: only diagonal", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "44"}),
-                 ("diag: only post", {"VO_DIAG": "1", "VO_DIAG_DEBUG": "28"})):
-    e = dict(os.environ, TAG=tag, VO_DIAG_WAVES=os.environ.get("VO_DIAG_WAVES", "7"), **env)
-    subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=e, timeout=300)
+VARIANTS = (("complete", 0), ("no cost", 4), ("no W+E", 8), ("no diagonal", 16), ("no post", 32), ("only cost", 56), ("only W+E", 52),
+            ("only diagonal", 44), ("only post", 28))
+engines = sys.argv[1].split(",") if len(sys.argv) > 1 else ["12"]
+for tag, dbg in VARIANTS:
+    for n in engines:
+        e = dict(os.environ, TAG="%s, %s engines" % (tag, n), VO_DIAG_DEBUG=str(dbg), VO_ENGINES=n)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=e, timeout=300)
