@@ -50,6 +50,11 @@ __device__ __forceinline__ uint32_t pk_sub_sat_u(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
+__device__ __forceinline__ uint32_t pk_shr2(uint32_t a)       // both halves >> 2 (v_pk_lshrrev_b16)
+{
+    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) >> (u16x2){2, 2});
+}
 __device__ __forceinline__ uint32_t pk_rep(int v) { return (uint32_t)(v & 0xFFFF) * 0x00010001u; }
 
 #define DPP(old, src, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, 0xf, 0xf, false))
@@ -169,7 +174,7 @@ __device__ __forceinline__ uint32_t bt_regs(uint32_t lw0, uint32_t lw1, const ui
         const uint32_t c0 = pk_sub_sat_u(U, V[c * 3 + 2]) | pk_sub_sat_u(V[c * 3 + 1], U);
         const uint32_t c1 = pk_sub_sat_u(V[c * 3 + 0], U1) | pk_sub_sat_u(U0, V[c * 3 + 0]);
         uint32_t m = pk_min(c0, c1);
-        if (c == 1) m = (m >> 2) & 0x3FFF3FFFu;
+        if (c == 1) m = pk_shr2(m);
         acc = pk_add(acc, m);
     }
     return acc;
@@ -200,6 +205,86 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
     uint32_t acc[XT];
 #pragma unroll
     for (int j = 0; j < XT; j++) acc[j] = pk_rep(g.P2);
+
+    // Interior strips (every column of the strip + halo inside the image, every lane's right-image positions inside the row):
+    // the six right-image planes of the row segment this wave needs -- positions Pmin .. Pmin + 126 + NC - 1 -- are staged in
+    // LDS once per row, split by parity (lane l reads position x - minD - 2 l: one parity per column, consecutive words for
+    // consecutive lanes, so the reads are conflict-free and their addresses are immediates on one register).  A column then
+    // costs its BT arithmetic only; the shift chains of the general path below (a v_readlane + v_mov + DPP shift per plane and
+    // column) remain for the strips at the image border.
+    {
+        constexpr int NJ = 64 + (NC - 1) / 2;                          // words per (plane, parity)
+        const int x0img = xa - SW2 + g.minX1;                          // image column of halo column 0
+        const int pmin = x0img - g.minD - lane0_d - 126;               // lane 63's position at halo column 0
+        const bool interior = xa >= SW2 && xa - SW2 + NC <= g.W1 && pmin >= 0 && pmin + 2 * NJ <= g.W;
+        if (interior) {
+            typedef __attribute__((address_space(3))) uint32_t lds_w;
+            typedef uint32_t w2 __attribute__((ext_vector_type(2)));
+            lds_w* const stage = (lds_w*)(s_ring + (size_t)(blockDim.x >> 6) * WIN * XT * 64) + (size_t)wv * 12 * NJ;
+            lds_w* const st_wr = stage + lane;                         // + (q * 2 + parity) * NJ  (+ 64 for the tail lanes)
+            const lds_w* const st_rd = stage + (63 - lane);            // + (q * 2 + (k & 1)) * NJ + (k >> 1)
+            const bool tail = lane < NJ - 64;
+            const int lrun = min(lane, NC - 1);
+            auto row_of = [&](int rr) { return (size_t)min(max(ya - SW2 + rr, 0), g.H - 1) * g.W; };
+            w2 pfm[6], pft[6];                                         // the next row's words, in flight while this row is computed
+            uint32_t pl0, pl1;
+            auto fetch = [&](int rr) {
+                const size_t rowi = row_of(rr);
+                const uint32_t* p = PR + rowi + pmin + 2 * lane;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    pfm[q] = *(const w2*)(p + (size_t)q * plane);
+                    pft[q] = *(const w2*)(p + (size_t)q * plane + (tail ? 128 : 0));
+                }
+                pl0 = PL[(rowi + x0img + lrun) * 2];
+                pl1 = PL[(rowi + x0img + lrun) * 2 + 1];
+            };
+            fetch(0);
+            for (int rr = 0; rr < nrows; rr++) {
+                const int slot = rr % WIN;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    st_wr[(q * 2) * NJ] = pfm[q].x;
+                    st_wr[(q * 2 + 1) * NJ] = pfm[q].y;
+                    if (tail) {
+                        st_wr[(q * 2) * NJ + 64] = pft[q].x;
+                        st_wr[(q * 2 + 1) * NJ + 64] = pft[q].y;
+                    }
+                }
+                const uint32_t plr0 = pl0, plr1 = pl1;
+                fetch(min(rr + 1, nrows - 1));
+                uint32_t pc[NC];
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    uint32_t V[6];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) V[q] = st_rd[(q * 2 + (k & 1)) * NJ + (k >> 1)];
+                    const uint32_t lw0 = (uint32_t)__builtin_amdgcn_readlane((int)plr0, k);
+                    const uint32_t lw1 = (uint32_t)__builtin_amdgcn_readlane((int)plr1, k);
+                    pc[k] = bt_regs(lw0, lw1, V);
+                }
+                uint32_t s = 0;
+#pragma unroll
+                for (int k = 0; k < WIN; k++) s = pk_add(s, pc[k]);
+#pragma unroll
+                for (int j = 0; j < XT; j++) {
+                    if (j > 0) s = pk_sub(pk_add(s, pc[j + WIN - 1]), pc[j - 1]);
+                    uint32_t* cell = ring + (size_t)(slot * XT + j) * 64;
+                    if (rr >= WIN) acc[j] = pk_sub(acc[j], *cell);
+                    acc[j] = pk_add(acc[j], s);
+                    *cell = s;
+                }
+                if (rr >= WIN - 1) {
+                    const int y = ya + rr - (WIN - 1);
+#pragma unroll
+                    for (int j = 0; j < XT; j++)
+                        if (2 * dpl < g.Dp)
+                            *(uint32_t*)(C + ((size_t)y * g.W1 + xa + j) * g.Dp + 2 * dpl) = pad ? MAXC2 : acc[j];
+                }
+            }
+            return;
+        }
+    }
 
     for (int rr = 0; rr < nrows; rr++) {
         const int r = min(max(ya - SW2 + rr, 0), g.H - 1);
@@ -1285,7 +1370,7 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
         const int nw = bx / 64;
 #define LAUNCH_SWEEP(XT, SW)                                                                                                   \
     hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(div_up(g.W1, XT), div_up(h, TY)), dim3(bx),                            \
-                       (size_t)nw * (2 * SW + 1) * XT * 64 * 4, ctx->stream, ctx->planesL, ctx->planesR, g, TY, ctx->C)
+                       (size_t)nw * ((2 * SW + 1) * XT * 64 + 12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->planesL, ctx->planesR, g, TY, ctx->C)
         if (dbg & 4) {
         } else
         switch (g.SW2) {

@@ -70,6 +70,21 @@ def test_sgbm_wide_disparity_ranges(oracle, ctx_wide, ndisp, ur, mode):
     assert np.array_equal(got, ref), "%d pixels differ" % int((got != ref).sum())
 
 
+@pytest.mark.parametrize("block,mind,ndisp", [(1, 0, 64), (3, -16, 48), (7, 0, 128), (7, 5, 32), (11, -16, 160), (11, 0, 16)])
+def test_sgbm_cost_volume_block_sizes_interior_and_border_strips(oracle, ctx_wide, block, mind, ndisp):
+    """The cost kernel stages the right-image planes of interior column strips in LDS and keeps lane-shift chains for the strips
+    at the image border (and wherever a lane's position would leave the row): every window size it is instantiated for, with
+    positive, zero and negative minDisparity, one and two waves of disparities -- the disparity stays bit-exact."""
+    c, L, R = _pair("C1", 3)
+    L, R = L[:120], R[:120]
+    p = dict(minDisparity=mind, numDisparities=ndisp, blockSize=block, P1=8 * block * block, P2=32 * block * block, disp12MaxDiff=1,
+             preFilterCap=63, uniquenessRatio=10, speckleWindowSize=0, speckleRange=0)
+    ctx_wide.set_sgbm(p, 0)
+    got = ctx_wide.sgbm_compute_host(L, R)
+    ref = oracle.sgbm_compute(L, R, p, 0)
+    assert np.array_equal(got, ref), "%d pixels differ" % int((got != ref).sum())
+
+
 def test_sgbm_random_noise_images(oracle, ctx_small):
     rng = np.random.default_rng(5)
     L = rng.integers(0, 256, (96, 160), dtype=np.uint8)
