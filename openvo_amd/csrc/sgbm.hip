@@ -220,35 +220,48 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
         if (interior) {
             typedef __attribute__((address_space(3))) uint32_t lds_w;
             typedef uint32_t w2 __attribute__((ext_vector_type(2)));
+            typedef __attribute__((address_space(3))) w2 lds_w2;
+            // staging layout: [parity][j][the six planes] -- a lane fetches the six planes of its position with three 8-byte reads
+            // at immediate offsets; consecutive lanes are 6 words apart, which spreads every 32-lane pass over all 64 banks
             lds_w* const stage = (lds_w*)(s_ring + (size_t)(blockDim.x >> 6) * WIN * XT * 64) + (size_t)wv * 12 * NJ;
-            lds_w* const st_wr = stage + lane;                         // + (q * 2 + parity) * NJ  (+ 64 for the tail lanes)
-            const lds_w* const st_rd = stage + (63 - lane);            // + (q * 2 + (k & 1)) * NJ + (k >> 1)
+            lds_w* const st_wr = stage + lane * 6;                     // + parity * NJ * 6  (+ 64 * 6 for the tail lanes)
+            const lds_w* const st_rd = stage + (63 - lane) * 6;        // + ((k & 1) * NJ + (k >> 1)) * 6
             const bool tail = lane < NJ - 64;
             const int lrun = min(lane, NC - 1);
             auto row_of = [&](int rr) { return (size_t)min(max(ya - SW2 + rr, 0), g.H - 1) * g.W; };
             w2 pfm[6], pft[6];                                         // the next row's words, in flight while this row is computed
             uint32_t pl0, pl1;
+            // buffer addressing: a resource descriptor (scalar registers) + a scalar byte offset that carries everything uniform
+            // (plane, row, strip) + one constant per-lane offset -- the loads and stores of the loop need no vector address
+            // arithmetic at all (global_load / global_store would spend ~50 64-bit vector adds per row on it)
+            const __amdgpu_buffer_rsrc_t rPR = __builtin_amdgcn_make_buffer_rsrc((void*)PR, 0, (int)(6 * plane * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rPL = __builtin_amdgcn_make_buffer_rsrc((void*)PL, 0, (int)(2 * plane * 4), 0x00020000);
+            const int voff = 8 * lane, voff_t = voff + (tail ? 512 : 0), vpl = 8 * lrun;
             auto fetch = [&](int rr) {
                 const size_t rowi = row_of(rr);
-                const uint32_t* p = PR + rowi + pmin + 2 * lane;
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
-                    pfm[q] = *(const w2*)(p + (size_t)q * plane);
-                    pft[q] = *(const w2*)(p + (size_t)q * plane + (tail ? 128 : 0));
+                    const int so = (int)(((size_t)q * plane + rowi + pmin) * 4);           // uniform
+                    pfm[q] = __builtin_amdgcn_raw_buffer_load_b64(rPR, voff, so, 0);
+                    pft[q] = __builtin_amdgcn_raw_buffer_load_b64(rPR, voff_t, so, 0);
                 }
-                pl0 = PL[(rowi + x0img + lrun) * 2];
-                pl1 = PL[(rowi + x0img + lrun) * 2 + 1];
+                const w2 lw = __builtin_amdgcn_raw_buffer_load_b64(rPL, vpl, (int)((rowi + x0img) * 8), 0);
+                pl0 = lw.x;
+                pl1 = lw.y;
             };
             fetch(0);
             for (int rr = 0; rr < nrows; rr++) {
                 const int slot = rr % WIN;
 #pragma unroll
-                for (int q = 0; q < 6; q++) {
-                    st_wr[(q * 2) * NJ] = pfm[q].x;
-                    st_wr[(q * 2 + 1) * NJ] = pfm[q].y;
-                    if (tail) {
-                        st_wr[(q * 2) * NJ + 64] = pft[q].x;
-                        st_wr[(q * 2 + 1) * NJ + 64] = pft[q].y;
+                for (int h = 0; h < 3; h++) {
+                    *(lds_w2*)(st_wr + 2 * h) = (w2){ pfm[2 * h].x, pfm[2 * h + 1].x };
+                    *(lds_w2*)(st_wr + NJ * 6 + 2 * h) = (w2){ pfm[2 * h].y, pfm[2 * h + 1].y };
+                }
+                if (tail) {
+#pragma unroll
+                    for (int h = 0; h < 3; h++) {
+                        *(lds_w2*)(st_wr + 64 * 6 + 2 * h) = (w2){ pft[2 * h].x, pft[2 * h + 1].x };
+                        *(lds_w2*)(st_wr + (NJ + 64) * 6 + 2 * h) = (w2){ pft[2 * h].y, pft[2 * h + 1].y };
                     }
                 }
                 const uint32_t plr0 = pl0, plr1 = pl1;
@@ -256,9 +269,9 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
                 uint32_t pc[NC];
 #pragma unroll
                 for (int k = 0; k < NC; k++) {
-                    uint32_t V[6];
-#pragma unroll
-                    for (int q = 0; q < 6; q++) V[q] = st_rd[(q * 2 + (k & 1)) * NJ + (k >> 1)];
+                    const lds_w* const sp = st_rd + ((k & 1) * NJ + (k >> 1)) * 6;
+                    const w2 va = *(const lds_w2*)sp, vb = *(const lds_w2*)(sp + 2), vc = *(const lds_w2*)(sp + 4);
+                    const uint32_t V[6] = { va.x, va.y, vb.x, vb.y, vc.x, vc.y };
                     const uint32_t lw0 = (uint32_t)__builtin_amdgcn_readlane((int)plr0, k);
                     const uint32_t lw1 = (uint32_t)__builtin_amdgcn_readlane((int)plr1, k);
                     pc[k] = bt_regs(lw0, lw1, V);
@@ -276,10 +289,13 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
                 }
                 if (rr >= WIN - 1) {
                     const int y = ya + rr - (WIN - 1);
+                    // (a descriptor per row segment: a 4K volume exceeds the 4 GB one descriptor can span; lanes past Dp are cut
+                    // off by its bounds check)
+                    int16_t* const crow = C + ((size_t)y * g.W1 + xa) * g.Dp;              // uniform
+                    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)crow, 0, XT * g.Dp * 2, 0x00020000);
 #pragma unroll
                     for (int j = 0; j < XT; j++)
-                        if (2 * dpl < g.Dp)
-                            *(uint32_t*)(C + ((size_t)y * g.W1 + xa + j) * g.Dp + 2 * dpl) = pad ? MAXC2 : acc[j];
+                        __builtin_amdgcn_raw_buffer_store_b32(pad ? MAXC2 : acc[j], rC, 2 * dpl < g.Dp ? 4 * dpl : 0x7FFFFFF0, j * g.Dp * 2, 0);
                 }
             }
             return;
