@@ -203,6 +203,19 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int 
     const int rx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
     const int ry[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
     const int v = p[0];
+    // a run of 9 on the 16-ring covers at least two of the four compass points (0, 4, 8, 12): when fewer than two of them are
+    // darker and fewer than two brighter the pixel cannot be a corner.  Most of an image fails this test; a wavefront whose
+    // 64 pixels all fail skips the other twelve loads and the arc test (the branch is wave-uniform).
+    {
+        int nd = 0, nb = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            const int q = p[ry[k] * w + rx[k]];
+            nd += q < v - FAST_T;
+            nb += q > v + FAST_T;
+        }
+        if (__ballot(nd >= 2 || nb >= 2) == 0ull) return 0;
+    }
     int d[16];
     unsigned dark = 0, bright = 0;
 #pragma unroll
