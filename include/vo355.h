@@ -88,9 +88,15 @@ int vo_prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* left, const uint8_t* 
  * (0 .. VO_NUM_HOST_STAGE-1) -- it first waits until the previous upload out of that buffer has finished, and it is the ONE
  * entry point that may run on another thread while the context is in use (it touches nothing but that buffer; two calls
  * must not name the same buffer concurrently); vo_prefetch_host_staged then starts upload + SGBM (+ ORB) of that buffer's
- * pair on a look-ahead engine like vo_prefetch_pair.  openvo_amd.StereoOdometer.run() drives them from a helper thread. */
-#define VO_NUM_HOST_STAGE 16
+ * pair on a look-ahead engine like vo_prefetch_pair.
+ * vo_host_stage_begin hands the same copy to ONE staging thread owned by the library and returns at once (a host written in
+ * an interpreted language then needs no thread of its own, and no interpreter lock changes hands per pair); the two images
+ * must stay untouched until vo_host_stage_wait, vo_prefetch_host_staged or vo_host_stage_fetch on that buffer has returned
+ * (each waits for the copy).  openvo_amd.StereoOdometer.run() keeps a few copies ahead of the pair it submits. */
+#define VO_NUM_HOST_STAGE 20
 int vo_host_stage_pair(vo_ctx* ctx, int buf, const uint8_t* left, const uint8_t* right, int w, int h, int channels);
+int vo_host_stage_begin(vo_ctx* ctx, int buf, const uint8_t* left, const uint8_t* right, int w, int h, int channels);
+int vo_host_stage_wait(vo_ctx* ctx, int buf);
 int vo_prefetch_host_staged(vo_ctx* ctx, int slot, int buf, int w, int h, int channels, int preprocessed);
 /* the pair staging buffer `buf` holds, copied back out (a caller that found no free slot keeps the pair on the host) */
 int vo_host_stage_fetch(vo_ctx* ctx, int buf, uint8_t* left, uint8_t* right, int w, int h, int channels);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VO355_LIB") or os.path.join(_HERE, "libvo355.so")   #
 _CSRC = os.path.join(_HERE, "csrc")
 
 VO_NUM_SLOTS = 28
-VO_NUM_HOST_STAGE = 16
+VO_NUM_HOST_STAGE = 20
 VO_NUM_MONO_ASYNC = 3
 SCHED_DIAG, SCHED_DIAG_RAGGED, SCHED_UNFUSED = 1, 2, 3
 T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose")
@@ -31,7 +31,7 @@ SYMBOLS = [
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_essential5", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
     "vo_sgbm_last_geometry", "vo_host_stage_pair", "vo_host_stage_fetch", "vo_prefetch_host_staged", "vo_lookahead_depth", "vo_lookahead_drop", "vo_sgbm_last_schedule", "vo_measure_copy", "vo_sgbm_sweep_status", "vo_sgbm_sweep_stats",
-    "vo_upload_mono", "vo_prefetch_staged_mono", "vo_mono_pair", "vo_mono_pair_begin", "vo_mono_pair_end", "vo_slot_ready",
+    "vo_upload_mono", "vo_prefetch_staged_mono", "vo_mono_pair", "vo_mono_pair_begin", "vo_mono_pair_end", "vo_slot_ready", "vo_host_stage_begin", "vo_host_stage_wait",
     "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_info", "vo_mgpu_last_error",
     "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
 ]
@@ -130,6 +130,8 @@ def lib():
         L.vo_prefetch_staged_mono.argtypes = [vp, ci, ci, ci]
         L.vo_mono_pair.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, ci, vp, vp, vp, vp, vp, ci]
         L.vo_slot_ready.argtypes = [vp, ci, vp]
+        L.vo_host_stage_begin.argtypes = [vp, ci, vp, vp, ci, ci, ci]
+        L.vo_host_stage_wait.argtypes = [vp, ci]
         L.vo_mono_pair_begin.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, ci, ci, vp]
         L.vo_mono_pair_end.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci]
         L.vo_device_count.argtypes = [vp]
@@ -239,6 +241,18 @@ class Context:
         if rc != 0:
             raise VoError(rc, "vo_host_stage_pair failed")      # (the context's error string belongs to the driving thread)
         return w, h, ch
+
+    def host_stage_begin(self, buf, left, right):
+        """The same copy on the library's own staging thread: returns at once with (w, h, ch, keep) -- `keep` holds the two
+        arrays, which must stay alive and untouched until prefetch_host_staged / host_stage_fetch / host_stage_wait on `buf`."""
+        ch = 3 if left.ndim == 3 else 1
+        left, right = _c(left, np.uint8), _c(right, np.uint8)
+        h, w = left.shape[:2]
+        self._ck(self._lib.vo_host_stage_begin(self._h, int(buf), _p(left), _p(right), w, h, ch))
+        return w, h, ch, (left, right)
+
+    def host_stage_wait(self, buf):
+        self._ck(self._lib.vo_host_stage_wait(self._h, int(buf)))
 
     def host_stage_fetch(self, buf, w, h, ch):
         shape = (h, w, 3) if ch == 3 else (h, w)

@@ -217,6 +217,11 @@ extern "C" void vo_destroy(vo_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stage_thread.joinable()) {
+        { std::lock_guard<std::mutex> lk(ctx->stage_mu); ctx->stage_stop = true; }
+        ctx->stage_cv.notify_all();
+        ctx->stage_thread.join();
+    }
     for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) if (ctx->la_stream[k]) (void)hipStreamSynchronize(ctx->la_stream[k]);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int s = 0; s <= VO_NUM_SLOTS; s++) {
@@ -374,8 +379,32 @@ static int check_slot(vo_ctx* ctx, int slot)
 }
 
 // upload one camera image into dst (gray, rectified)
+// Image bytes out of pinned host memory by a kernel (the GPU reads them over the host link itself).  An asynchronous
+// hipMemcpy from pinned memory goes to a DMA engine instead, and every hand-over between that engine's queue and the compute
+// queue of the look-ahead engine costs the stream tens of microseconds -- with a dozen engines uploading, the from-host rate
+// fell to 0.6-0.8 of the resident rate.
+typedef uint32_t ingest_u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_ingest_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t bytes)
+{
+    const size_t n16 = bytes / 16, stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < n16; i += stride)
+        ((ingest_u32x4*)dst)[i] = __builtin_nontemporal_load((const ingest_u32x4*)src + i);
+    for (size_t i = n16 * 16 + i0; i < bytes; i += stride) dst[i] = src[i];
+}
+
+static int ingest_bytes(vo_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t bytes, hipMemcpyKind kind, bool by_kernel)
+{
+    if (by_kernel && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0)) {
+        const int blocks = (int)((bytes / 16 + 255) / 256 < 2048 ? (bytes / 16 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_ingest_copy, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, ctx->stream, src, dst, bytes);
+        return VO_OK;
+    }
+    VO_HIP(ctx, hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+    return VO_OK;
+}
+
 static int ingest(vo_ctx* ctx, int cam, const uint8_t* host, int w, int h, int channels, int preprocessed, uint8_t* dst,
-                  uint8_t* stage, hipMemcpyKind kind = hipMemcpyHostToDevice)
+                  uint8_t* stage, hipMemcpyKind kind = hipMemcpyHostToDevice, bool by_kernel = false)
 {
     const size_t n = (size_t)w * h;
     const bool need_remap = !preprocessed;
@@ -383,10 +412,10 @@ static int ingest(vo_ctx* ctx, int cam, const uint8_t* host, int w, int h, int c
         return vo_fail(ctx, VO_E_STATE, "rectification maps for camera %d not set for %dx%d", cam, w, h);
     uint8_t* gray = need_remap ? stage + n * 3 : dst;  // gray staging behind the colour staging
     if (channels == 3) {
-        VO_HIP(ctx, hipMemcpyAsync(stage, host, n * 3, kind, ctx->stream));
+        if (int rcb = ingest_bytes(ctx, stage, host, n * 3, kind, by_kernel)) return rcb;
         hipLaunchKernelGGL(k_bgr2gray, dim3(div_up((int)n, 256)), dim3(256), 0, ctx->stream, stage, (int)n, gray);
     } else {
-        VO_HIP(ctx, hipMemcpyAsync(gray, host, n, kind, ctx->stream));
+        if (int rcb = ingest_bytes(ctx, gray, host, n, kind, by_kernel)) return rcb;
     }
     if (need_remap)
         hipLaunchKernelGGL(k_remap, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, gray, w, h, ctx->map1[cam],
@@ -605,10 +634,12 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
         rc = slot_before_overwrite(ctx, f);
         if (!rc) {
             StageTimer t(ctx, VO_T_UPLOAD);
-            rc = ingest(ctx, 0, srcL, w, h, channels, preprocessed, f.left, ctx->stage_in, kind);
-            if (!rc) rc = ingest(ctx, 1, srcR, w, h, channels, preprocessed, f.right, ctx->stage_in, kind);
+            const bool pinned_src = hs != nullptr || from_host;   // (the library's own pinned staging either way)
+            rc = ingest(ctx, 0, srcL, w, h, channels, preprocessed, f.left, ctx->stage_in, kind, pinned_src);
+            if (!rc) rc = ingest(ctx, 1, srcR, w, h, channels, preprocessed, f.right, ctx->stage_in, kind, pinned_src);
         }
         if (!rc && hs) {
+            std::lock_guard<std::mutex> lk(ctx->stage_mu);
             if (hipEventRecord(hs->h2d_done, ctx->stream) == hipSuccess) hs->valid = true;
             else rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
         } else if (!rc && from_host) {
@@ -712,24 +743,102 @@ extern "C" int vo_prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* left, cons
     return prefetch_pair(ctx, slot, left, right, true, w, h, channels, preprocessed);
 }
 
-// May run on a helper thread of the caller while another thread drives the context: it touches nothing but staging
-// buffer `buf` (and reports failures by code only: the context's error string belongs to the driving thread).
+static int host_stage_alloc(vo_ctx* ctx)
+{
+    // first use of the staging path: every buffer at once (a pinned allocation takes about a millisecond -- not something to
+    // pay inside a stream, buffer by buffer)
+    for (vo_ctx::HostStage& q : ctx->host_stage) {
+        if (q.pinned) continue;
+        if (hipHostMalloc((void**)&q.pinned, ctx->stage_bytes * 2, hipHostMallocDefault) != hipSuccess) return VO_E_HIP;
+        if (hipEventCreateWithFlags(&q.h2d_done, hipEventDisableTiming) != hipSuccess) return VO_E_HIP;
+    }
+    return VO_OK;
+}
+
+// body of the staging thread: one copy at a time, in the order asked for
+static void host_stage_loop(vo_ctx* ctx)
+{
+    (void)hipSetDevice(ctx->device);
+    for (;;) {
+        vo_ctx::StageJob job;
+        hipEvent_t wait_for = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(ctx->stage_mu);
+            ctx->stage_cv.wait(lk, [&] { return ctx->stage_stop || !ctx->stage_jobs.empty(); });
+            if (ctx->stage_stop) return;
+            job = ctx->stage_jobs.front();
+            ctx->stage_jobs.pop_front();
+            vo_ctx::HostStage& hs = ctx->host_stage[job.buf];
+            if (hs.valid) wait_for = hs.h2d_done;     // the previous upload out of this buffer
+        }
+        int rc = VO_OK;
+        if (wait_for && hipEventSynchronize(wait_for) != hipSuccess) rc = VO_E_HIP;
+        if (!rc) {
+            vo_ctx::HostStage& hs = ctx->host_stage[job.buf];
+            memcpy(hs.pinned, job.left, job.per);
+            memcpy(hs.pinned + job.per, job.right, job.per);
+        }
+        {
+            std::lock_guard<std::mutex> lk(ctx->stage_mu);
+            ctx->host_stage[job.buf].state = rc;
+        }
+        ctx->stage_cv.notify_all();
+    }
+}
+
+// until the copy begun into `buf` has finished (at once when none is pending); its status
+static int host_stage_wait(vo_ctx* ctx, int buf)
+{
+    std::unique_lock<std::mutex> lk(ctx->stage_mu);
+    vo_ctx::HostStage& hs = ctx->host_stage[buf];
+    ctx->stage_cv.wait(lk, [&] { return hs.state != 1; });
+    const int rc = hs.state;
+    hs.state = 0;
+    return rc;
+}
+
+// The copy of a host pair into pinned staging buffer `buf`, handed to the library's staging thread: returns at once.  The two
+// images must stay untouched until vo_host_stage_wait / vo_prefetch_host_staged / vo_host_stage_fetch on that buffer returns.
+extern "C" int vo_host_stage_begin(vo_ctx* ctx, int buf, const uint8_t* left, const uint8_t* right, int w, int h, int channels)
+{
+    if (!ctx || buf < 0 || buf >= vo_ctx::N_HOST_STAGE || !left || !right || (channels != 1 && channels != 3))
+        return vo_fail(ctx, VO_E_ARG, "vo_host_stage_begin: bad argument");
+    if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context %dx%d", w, h, ctx->max_w, ctx->max_h);
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    if (host_stage_alloc(ctx)) return vo_fail(ctx, VO_E_HIP, "pinned staging memory: allocation failed");
+    {
+        std::lock_guard<std::mutex> lk(ctx->stage_mu);
+        vo_ctx::HostStage& hs = ctx->host_stage[buf];
+        if (hs.state == 1) return vo_fail(ctx, VO_E_STATE, "vo_host_stage_begin: a copy into buffer %d is still pending", buf);
+        hs.state = 1;
+        ctx->stage_jobs.push_back({ buf, left, right, (size_t)w * h * channels });
+        if (!ctx->stage_thread.joinable()) ctx->stage_thread = std::thread(host_stage_loop, ctx);
+    }
+    ctx->stage_cv.notify_all();
+    return VO_OK;
+}
+
+extern "C" int vo_host_stage_wait(vo_ctx* ctx, int buf)
+{
+    if (!ctx || buf < 0 || buf >= vo_ctx::N_HOST_STAGE) return vo_fail(ctx, VO_E_ARG, "vo_host_stage_wait: bad argument");
+    const int rc = host_stage_wait(ctx, buf);
+    return rc ? vo_fail(ctx, rc, "the copy into staging buffer %d failed", buf) : VO_OK;
+}
+
+// The same copy done by the calling thread.  May run on a helper thread of the caller while another thread drives the
+// context: it touches nothing but staging buffer `buf` (and reports failures by code only: the context's error string
+// belongs to the driving thread).
 extern "C" int vo_host_stage_pair(vo_ctx* ctx, int buf, const uint8_t* left, const uint8_t* right, int w, int h, int channels)
 {
     if (!ctx || buf < 0 || buf >= vo_ctx::N_HOST_STAGE || !left || !right || (channels != 1 && channels != 3)) return VO_E_ARG;
     if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return VO_E_CAP;
     if (hipSetDevice(ctx->device) != hipSuccess) return VO_E_HIP;
+    if (host_stage_alloc(ctx)) return VO_E_HIP;
+    if (int rcw = host_stage_wait(ctx, buf)) return rcw;
     vo_ctx::HostStage& hs = ctx->host_stage[buf];
-    if (!hs.pinned) {
-        // first use of the staging path: every buffer at once (a pinned allocation takes about a millisecond -- not something
-        // to pay inside a stream, buffer by buffer); only the thread that stages ever gets here
-        for (vo_ctx::HostStage& q : ctx->host_stage) {
-            if (q.pinned) continue;
-            if (hipHostMalloc((void**)&q.pinned, ctx->stage_bytes * 2, hipHostMallocDefault) != hipSuccess) return VO_E_HIP;
-            if (hipEventCreateWithFlags(&q.h2d_done, hipEventDisableTiming) != hipSuccess) return VO_E_HIP;
-        }
-    }
-    if (hs.valid && hipEventSynchronize(hs.h2d_done) != hipSuccess) return VO_E_HIP;   // the previous upload out of this buffer
+    hipEvent_t wait_for = nullptr;
+    { std::lock_guard<std::mutex> lk(ctx->stage_mu); if (hs.valid) wait_for = hs.h2d_done; }
+    if (wait_for && hipEventSynchronize(wait_for) != hipSuccess) return VO_E_HIP;   // the previous upload out of this buffer
     const size_t per = (size_t)w * h * channels;
     memcpy(hs.pinned, left, per);
     memcpy(hs.pinned + per, right, per);
@@ -742,6 +851,7 @@ extern "C" int vo_host_stage_fetch(vo_ctx* ctx, int buf, uint8_t* left, uint8_t*
     if (!ctx || buf < 0 || buf >= vo_ctx::N_HOST_STAGE || !left || !right || (channels != 1 && channels != 3)) return VO_E_ARG;
     vo_ctx::HostStage& hs = ctx->host_stage[buf];
     if (!hs.pinned || (size_t)w * h * channels > ctx->stage_bytes) return VO_E_STATE;
+    if (int rcw = host_stage_wait(ctx, buf)) return rcw;
     const size_t per = (size_t)w * h * channels;
     memcpy(left, hs.pinned, per);
     memcpy(right, hs.pinned + per, per);
@@ -756,7 +866,8 @@ extern "C" int vo_prefetch_host_staged(vo_ctx* ctx, int slot, int buf, int w, in
     if (w > ctx->max_w || h > ctx->max_h || w < 16 || h < 16) return vo_fail(ctx, VO_E_CAP, "image %dx%d exceeds context %dx%d", w, h, ctx->max_w, ctx->max_h);
     if (!ctx->sg.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");
     vo_ctx::HostStage& hs = ctx->host_stage[buf];
-    if (!hs.pinned) return vo_fail(ctx, VO_E_STATE, "staging buffer %d has not been filled (vo_host_stage_pair)", buf);
+    if (!hs.pinned) return vo_fail(ctx, VO_E_STATE, "staging buffer %d has not been filled (vo_host_stage_pair / vo_host_stage_begin)", buf);
+    if ((rc = host_stage_wait(ctx, buf))) return vo_fail(ctx, rc, "the copy into staging buffer %d failed", buf);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     const size_t per = (size_t)w * h * channels;
     return prefetch_pair(ctx, slot, hs.pinned, hs.pinned + per, true, w, h, channels, preprocessed, &hs);

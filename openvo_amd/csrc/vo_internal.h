@@ -6,6 +6,10 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <deque>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include "../../include/vo355.h"
 
 #define VO_ORB_LEVELS 8
@@ -95,7 +99,7 @@ struct vo_ctx {
     bool la_orb = false;
     int la_orb_params[4] = {0, 0, 0, 0};
     int32_t* slot_words = nullptr;   // pinned, one word per slot (keypoint counts of pending runs)
-    int n_engines = 12;              // VO_ENGINES (needs GPU_MAX_HW_QUEUES >= engines + 4: streams sharing a hardware queue serialise)
+    int n_engines = 16;              // VO_ENGINES (needs GPU_MAX_HW_QUEUES >= engines + 4: streams sharing a hardware queue serialise)
     int next_engine = 0;
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;
     std::string err;
@@ -218,7 +222,19 @@ struct vo_ctx {
     // pinned staging buffers for host images filled AHEAD by a helper thread of the caller (vo_host_stage_pair) and consumed by
     // vo_prefetch_host_staged on the thread that drives the context: the launching thread does no memcpy
     static const int N_HOST_STAGE = VO_NUM_HOST_STAGE;
-    struct HostStage { uint8_t* pinned = nullptr; hipEvent_t h2d_done = nullptr; bool valid = false; } host_stage[VO_NUM_HOST_STAGE];
+    // `state` (under stage_mu): 0 = idle or filled, 1 = a copy into the buffer is queued or running on the library's staging
+    // thread, < 0 = that copy failed (VO_E_*).  `valid` / `h2d_done` are written by the driving thread (the upload out of
+    // the buffer has been enqueued) and read by the staging thread before it overwrites the buffer: under stage_mu too.
+    struct HostStage { uint8_t* pinned = nullptr; hipEvent_t h2d_done = nullptr; bool valid = false; int state = 0; } host_stage[VO_NUM_HOST_STAGE];
+    // vo_host_stage_begin: the copy of a host pair into pinned memory runs on ONE thread owned by the library (started on first
+    // use, joined by vo_destroy), so that a driving thread written in an interpreted language never shares its interpreter
+    // lock with a copying thread
+    struct StageJob { int buf; const uint8_t *left, *right; size_t per; };
+    std::thread stage_thread;
+    std::mutex stage_mu;
+    std::condition_variable stage_cv;
+    std::deque<StageJob> stage_jobs;
+    bool stage_stop = false;
 
     // inputs staged in HBM
     uint8_t* staged = nullptr;

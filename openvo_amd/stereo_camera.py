@@ -130,8 +130,8 @@ class StereoCamera:
         self._slot_owner = [None] * _native.VO_NUM_SLOTS   # weak bookkeeping: FrameHandle per slot
         self._slot_gen = [0] * _native.VO_NUM_SLOTS        # bumped whenever a slot receives a new pair
         self._next_slot = 0
-        # staged pairs: how many following pairs run their SGBM ahead (default 14, at most VO_NUM_SLOTS - 3; env VO_LOOKAHEAD overrides)
-        self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "14"))
+        # staged pairs: how many following pairs run their SGBM ahead (default 18, at most VO_NUM_SLOTS - 3; env VO_LOOKAHEAD overrides)
+        self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "18"))
         self._lookahead = []         # [((index, preprocessed), slot, (w, h))] of the pairs in flight
         self._n_staged = 0
 

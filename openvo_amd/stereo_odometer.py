@@ -176,51 +176,54 @@ class StereoOdometer:
         update()'s result per pair, in order.  Not in the reference (whose update() takes one host pair per call,
         stereo_odometer.py:115-116).
 
-        The copy of each pair into pinned staging memory runs on a helper thread (the native call releases the GIL), a few
-        pairs ahead, so the thread that launches kernels never touches image bytes; pairs whose two images differ in
-        channel count go through StereoCamera.submit() instead."""
-        import queue as _queue
-        import threading
+        The copy of each pair into pinned staging memory runs on the library's own staging thread (vo_host_stage_begin), one
+        pair ahead of the pair being submitted: it overlaps this thread's kernel launches and waits, this thread never touches
+        image bytes, and no second Python thread competes for the interpreter lock.  The caller may refill the arrays it
+        yielded as soon as it is asked for the next pair (a copy is waited for before the iterator is advanced).  Pairs whose
+        two images differ in channel count go through StereoCamera.submit() instead."""
         from collections import deque
         cam, ctx = self.stereo, self.stereo._ctx
         depth = int(cam.lookahead if depth is None else depth)
         nbuf = _native.VO_NUM_HOST_STAGE
-        staged, free, stop = _queue.Queue(), threading.Semaphore(nbuf - 1), threading.Event()
+        it = iter(pairs)
+        copying, queue = deque(), deque()            # staged (or being staged) and not yet submitted / submitted and not yet consumed
+        state = {"k": 0, "done": False, "inflight": None}
 
-        def stager():
+        def stage_next():
+            if state["inflight"] is not None:
+                ctx.host_stage_wait(state["inflight"])                   # its source arrays are the caller's again
+                state["inflight"] = None
             try:
-                for k, (L, R) in enumerate(pairs):
-                    L, R = np.asarray(L), np.asarray(R)
-                    if L.ndim != R.ndim or L.shape != R.shape:
-                        staged.put((None, L.copy(), R.copy()))   # mixed inputs: the driving thread converts them
-                        continue
-                    free.acquire()                               # a buffer whose previous pair has been handed to the engines
-                    if stop.is_set():
-                        return
-                    staged.put((ctx.host_stage_pair(k % nbuf, L, R), k % nbuf, None))
-            except BaseException as e:                           # surfaces on the consuming thread
-                staged.put(e)
-            finally:
-                staged.put(None)
+                L, R = next(it)
+            except StopIteration:
+                state["done"] = True
+                return
+            L, R = np.asarray(L), np.asarray(R)
+            if L.ndim != R.ndim or L.shape != R.shape:
+                copying.append((None, L.copy(), R.copy()))               # mixed inputs: converted when submitted
+            else:
+                buf = state["k"] % nbuf
+                copying.append((buf,) + ctx.host_stage_begin(buf, L, R))
+                state["inflight"] = buf
+                state["k"] += 1
 
-        th = threading.Thread(target=stager, name="vo355-host-stager", daemon=True)
-        th.start()
-        queue, done = deque(), False
+        def keep_one_ahead():
+            while not state["done"] and len(copying) < 2:
+                stage_next()
+
         try:
             while True:
-                while len(queue) <= depth and not done:
-                    item = staged.get()
-                    if item is None:
-                        done = True
-                        break
-                    if isinstance(item, BaseException):
-                        raise item
-                    tok, a, b = item
-                    if tok is None:
-                        queue.append(cam.submit(a, b, preprocessed=self.preprocessed_frames))
+                keep_one_ahead()
+                while len(queue) <= depth and copying and (len(copying) >= 2 or state["done"]):
+                    item = copying.popleft()
+                    if item[0] is None:
+                        queue.append(cam.submit(item[1], item[2], preprocessed=self.preprocessed_frames))
                     else:
-                        queue.append(cam.submit_staged(a, tok[0], tok[1], tok[2], self.preprocessed_frames))
-                        free.release()                           # (its upload is queued; the stager waits for it before reusing the buffer)
+                        buf, w, h, ch, _keep = item
+                        if state["inflight"] == buf:
+                            state["inflight"] = None                     # (submit_staged waits for the copy)
+                        queue.append(cam.submit_staged(buf, w, h, ch, self.preprocessed_frames))
+                    keep_one_ahead()
                 if not queue:
                     return
                 head = queue.popleft()
@@ -230,9 +233,8 @@ class StereoOdometer:
                 finally:
                     self._next_hint = ()
         finally:
-            stop.set()
-            free.release()
-            th.join(timeout=30.0)
+            if state["inflight"] is not None:                            # a copy begun and never submitted: its sources may go away now
+                ctx.host_stage_wait(state["inflight"])
 
     _SEAMS = ("point_clouds", "point_cloud_transform", "rigid_body_filter", "bilinear_interpolate_pixels",
               "_estimate", "_gate")
