@@ -4,7 +4,7 @@ BASELINE sizes."""
 import numpy as np
 import pytest
 
-from openvo_amd import StereoCamera, StereoOdometer
+from openvo_amd import StereoCamera, StereoOdometer, _native
 from openvo_amd.synth import Corridor
 
 pytestmark = pytest.mark.gpu
@@ -461,6 +461,32 @@ def test_copy_ceiling_probe_is_sane_and_leaves_the_context_usable(oracle):
     assert np.array_equal(cam.stereoSGBM.compute(L, R), before)
     with pytest.raises(Exception):
         cam._ctx.measure_copy(0, 0, False)                       # reps must be positive
+
+
+def test_host_staging_thread_begin_wait_fetch_and_prefetch():
+    """vo_host_stage_begin hands the copy into pinned staging to the library's own thread: a buffer read back (fetch waits for
+    the copy) holds the pair; a pair prefetched straight after begin (no explicit wait) gives the disparity of the plain host
+    path; a buffer refilled while its previous upload may still be running (the staging thread waits for that upload) does
+    too; wait on an idle buffer returns at once; bad arguments are refused."""
+    c, cam = _rig("C1", max_keypoints=500)
+    ctx = cam._ctx
+    pairs = c.pairs(0, 6)
+    want = [cam.stereoSGBM.compute(L, R) for L, R in pairs]
+    w, h, ch, keep = ctx.host_stage_begin(2, *pairs[0])
+    assert (w, h, ch) == (c.w, c.h, 1)
+    Lb, Rb = ctx.host_stage_fetch(2, w, h, ch)
+    assert np.array_equal(Lb, pairs[0][0]) and np.array_equal(Rb, pairs[0][1])
+    ctx.host_stage_wait(2)
+    ctx.host_stage_wait(7)                                            # never used: nothing pending
+    for k, (L, R) in enumerate(pairs):                                # one buffer over and over: every refill meets the last upload
+        w, h, ch, keep = ctx.host_stage_begin(5, L, R)
+        ctx.prefetch_host_staged(3 + (k & 1), 5, w, h, ch, True)
+        assert np.array_equal(ctx.download_left(3 + (k & 1), L.shape), L), k
+        assert np.array_equal(ctx.download_disparity_f32(3 + (k & 1), L.shape), want[k].astype(np.float32) / 16.0), k
+    with pytest.raises(Exception):
+        ctx.host_stage_begin(_native.VO_NUM_HOST_STAGE, *pairs[0])
+    with pytest.raises(Exception):
+        ctx.host_stage_wait(-1)
 
 
 def test_lookahead_depth_counts_what_is_really_in_flight():
