@@ -63,6 +63,16 @@ def _save_plain(path, d):
         raise ValueError("%s: expected a .json or .npz file" % path)
 
 
+def _rotation_3x3(R):
+    """'R' of a rectification file: a 3x3 matrix, or a rotation vector (3 numbers) converted like cv2.Rodrigues"""
+    R = np.asarray(R, np.float64)
+    if R.size == 9:
+        return R.reshape(3, 3)
+    if R.size != 3:
+        raise ValueError("rectification 'R' must be a 3x3 matrix or a rotation vector of 3 numbers")
+    return calib.rodrigues_vec_to_mat(R.reshape(3))
+
+
 class StereoCamera:
     @classmethod
     def from_pfiles(cls, left_cam_file, right_cam_file, rect_file, sgbm_file, img_size, **kw):
@@ -94,7 +104,7 @@ class StereoCamera:
         sgbm = {k: int(np.asarray(sgbm[k]).reshape(-1)[0]) for k in cls.SGBM_KEYS}
         return cls(np.asarray(cam_l["K"], np.float64), np.asarray(cam_l["dist"], np.float64),
                    np.asarray(cam_r["K"], np.float64), np.asarray(cam_r["dist"], np.float64),
-                   {"R": np.asarray(rect["R"], np.float64), "T": np.asarray(rect["T"], np.float64)}, sgbm, img_size, **kw)
+                   {"R": _rotation_3x3(rect["R"]), "T": np.asarray(rect["T"], np.float64)}, sgbm, img_size, **kw)
 
     @staticmethod
     def save_files(left_cam_file, right_cam_file, rect_file, sgbm_file, K_left, dist_left, K_right, dist_right,

@@ -83,6 +83,23 @@ def test_from_files_safe_formats_round_trip(tmp_path, ext):
         assert set(json.load(open(files[3]))) == set(SGBM)
 
 
+def test_from_files_accepts_a_rotation_vector_as_documented(tmp_path):
+    """'R' of the rectification file may be the 3-number rotation vector (what cv2.stereoCalibrate users often keep):
+    the camera built from it equals the one built from the 3x3 matrix; anything else is refused."""
+    from openvo_amd import calib
+    files = [tmp_path / ("%s.json" % n) for n in ("left", "right", "rect", "sgbm")]
+    rvec = calib.rodrigues_mat_to_vec(np.asarray(RECT["R"], np.float64))
+    StereoCamera.save_files(*files, K_L, D_L, K_R, D_R, {"R": rvec, "T": RECT["T"]}, SGBM)
+    a = StereoCamera.from_files(*files, (640, 480), context=FakeContext())
+    StereoCamera.save_files(*files, K_L, D_L, K_R, D_R, RECT, SGBM)
+    b = StereoCamera.from_files(*files, (640, 480), context=FakeContext())
+    assert np.allclose(a.Q, b.Q, rtol=0, atol=1e-9) and a.valid_region_left == b.valid_region_left
+    assert np.abs(a.map_left_1.astype(np.int32) - b.map_left_1.astype(np.int32)).max() <= 1
+    StereoCamera.save_files(*files, K_L, D_L, K_R, D_R, {"R": np.zeros(4), "T": RECT["T"]}, SGBM)
+    with pytest.raises(ValueError):
+        StereoCamera.from_files(*files, (640, 480), context=FakeContext())
+
+
 def test_from_files_rejects_pickles_and_incomplete_files(tmp_path):
     good = [tmp_path / ("%s.json" % n) for n in ("left", "right", "rect", "sgbm")]
     StereoCamera.save_files(*good, K_L, D_L, K_R, D_R, RECT, SGBM)
