@@ -326,7 +326,7 @@ def bench_c5(args, group, device, K_steps, W):
     # per-stage device times from an untimed pass of the same steps with HIP events on (event packets around every stage of
     # every stream cost throughput: they stay out of the timed region)
     n_ev = min(K_steps, 40)
-    odo.reset_lookahead()
+    odo.restart()                # (the pass replays the timed frames: its first one is a first frame again)
     odo.speculate = 0            # one pair's chain at a time: a stage's event pair then brackets that stage's own kernels only
     ctx.synchronize()
     ctx.enable_timing(True)

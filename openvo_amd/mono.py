@@ -99,6 +99,14 @@ class MonoOdometer:
         the reference frame alone.  For measurements: nothing computed before the clock starts is used after it."""
         self._drop_ahead()
 
+    def restart(self):
+        """Forget the reference frame too: the next update() is a first frame again (the pose accumulated so far stays)."""
+        self._drop_ahead()
+        if self._ref is not None:
+            self._free.append(self._ref[0])
+            self._ref = None
+        self.last = None
+
     def _drop_ahead(self):
         self._void_open()
         for s in self._ahead.values():                            # the predictions are void (their extractions may still run:
