@@ -553,17 +553,19 @@ class Context:
         E = np.zeros(9, np.float64)
         c3 = np.zeros(3, np.int32)
         cap = self.kp_cap
-        mask = np.empty(cap, np.uint8) if want_matches else None
-        q = np.empty(cap, np.int32) if want_matches else None
-        t = np.empty(cap, np.int32) if want_matches else None
-        xy = np.empty((cap, 2), np.float32) if want_matches else None
-        self._ck(self._lib.vo_mono_pair_end(self._h, int(ticket), _p(E), _p(c3), _p(mask) if want_matches else None,
-                                            _p(q) if want_matches else None, _p(t) if want_matches else None,
-                                            _p(xy) if want_matches else None, cap))
+        if want_matches:
+            # one set of output arrays per context, reused call after call (the slices handed out are copies)
+            buf = self.__dict__.get("_mono_out")
+            if buf is None or len(buf[0]) != cap:
+                buf = self._mono_out = (np.empty(cap, np.uint8), np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty((cap, 2), np.float32))
+            mask, q, t, xy = buf
+            self._ck(self._lib.vo_mono_pair_end(self._h, int(ticket), _p(E), _p(c3), _p(mask), _p(q), _p(t), _p(xy), cap))
+        else:
+            self._ck(self._lib.vo_mono_pair_end(self._h, int(ticket), _p(E), _p(c3), None, None, None, None, cap))
         out = {"E": E.reshape(3, 3), "matches": int(c3[0]), "best_iter": int(c3[1]), "best_count": int(c3[2])}
         if want_matches:
             m = int(c3[0])
-            out.update(mask=mask[:m].copy(), q=q[:m].copy(), t=t[:m].copy(), xy_b=xy)
+            out.update(mask=mask[:m].copy(), q=q[:m].copy(), t=t[:m].copy(), xy_b=xy.copy())
         return out
 
     def ransac_pnp(self, pts3d, pts2d, K4, iters=5000, thr=2.0, seed=4321, want_counts=False):
