@@ -189,7 +189,14 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int dpl = threadIdx.x;                  // disparity pair index (padded layout)
     const bool pad = 2 * dpl >= g.D;
-    const int xa = blockIdx.x * XT, ya = blockIdx.y * TY;
+    // XCD-aware tile order: consecutive workgroups go to the 8 XCDs round-robin, each with an L2 of its own -- give every XCD a
+    // contiguous band of tile rows, so that a row of the image planes is fetched into one L2 (plus the bands' halos), not eight
+    // (the launch is one-dimensional: 8 x ceil(tiles / 8) workgroups)
+    const int gx = (g.W1 + XT - 1) / XT, total = gx * ((g.H + TY - 1) / TY);
+    const int chunk = (total + 7) >> 3, tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tile >= total) return;
+    const int tbx = tile % gx, tby = tile / gx;
+    const int xa = tbx * XT, ya = tby * TY;
     const size_t plane = (size_t)g.W * g.H;
     uint32_t* ring = s_ring + (size_t)wv * WIN * XT * 64 + lane;
     const int yend = min(ya + TY, g.H);
@@ -1385,7 +1392,7 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
         const int TY = ctx->tune_sweep_ty;
         const int nw = bx / 64;
 #define LAUNCH_SWEEP(XT, SW)                                                                                                   \
-    hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(div_up(g.W1, XT), div_up(h, TY)), dim3(bx),                            \
+    hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(8 * div_up(div_up(g.W1, XT) * div_up(h, TY), 8)), dim3(bx),            \
                        (size_t)nw * ((2 * SW + 1) * XT * 64 + 12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->planesL, ctx->planesR, g, TY, ctx->C)
         if (dbg & 4) {
         } else
