@@ -106,6 +106,28 @@ def test_unrectified_colour_input(oracle):
     assert np.array_equal(np.rint(np.asarray(disp) * 16).astype(np.int16), ref16[vr[1]:vr[3], vr[0]:vr[2]])
 
 
+def test_raw_colour_pairs_through_run_equal_plain_updates():
+    """The reference's default input: unrectified BGR pairs (preprocessed_frames=False).  Handed to run() they are copied into
+    pinned staging by the library's thread, read from there by the ingest kernel (3 bytes per pixel), converted and remapped on a
+    look-ahead engine -- poses bit-identical to plain update(left, right) calls on the same arrays."""
+    from openvo_amd import calib
+    c = Corridor("C1")
+    dist = np.array([-0.05, 0.01, 0.0003, -0.0002, 0.0])
+    rect = {"R": calib.rodrigues_vec_to_mat([0.001, 0.002, -0.001]), "T": np.array([-c.B, 0.0, 0.0])}
+    cam = StereoCamera(c.K(), dist, c.K(), dist, rect, c.sgbm_params(), (c.w, c.h), max_keypoints=500)
+    frames = []
+    for L, R in c.pairs(0, 8):
+        frames.append((np.ascontiguousarray(np.stack([L, L, L], -1)), np.ascontiguousarray(np.stack([R, R, R], -1))))
+    kw = dict(rigidity_threshold=0.1, outlier_threshold=0.02)
+    plain = StereoOdometer(cam, **kw)
+    want = [(plain.update(L, R), plain.c_T_w.copy()) for L, R in frames]
+    odo = StereoOdometer(cam, **kw)
+    got = [(ok, odo.c_T_w.copy()) for ok in odo.run(iter(frames), depth=4)]
+    assert len(got) == len(want) and sum(a for a, _ in got) >= 6
+    for (a, Ta), (b, Tb) in zip(got, want):
+        assert a == b and np.array_equal(Ta, Tb)
+
+
 def test_frame_eviction_keeps_results():
     """Holding more frames than device slots moves the oldest to host memory transparently."""
     c, cam = _rig("T0", max_keypoints=300)
