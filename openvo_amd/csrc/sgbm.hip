@@ -181,13 +181,21 @@ __device__ __forceinline__ uint32_t bt_regs(uint32_t lw0, uint32_t lw1, const ui
 }
 
 template <int XT, int SW2>
-__device__ __forceinline__ void cost_tile(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR, const SgbmGeom& g, int TY,
-                                          int16_t* __restrict__ C, uint32_t* s_ring, int tbx, int tby)
+__global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR,
+                                                        SgbmGeom g, int TY, int16_t* __restrict__ C)
 {
     constexpr int WIN = 2 * SW2 + 1, NC = XT + 2 * SW2;
+    extern __shared__ uint32_t s_ring[];  // [waves][WIN][XT][64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int dpl = threadIdx.x;                  // disparity pair index (padded layout)
     const bool pad = 2 * dpl >= g.D;
+    // XCD-aware tile order: consecutive workgroups go to the 8 XCDs round-robin, each with an L2 of its own -- give every XCD a
+    // contiguous band of tile rows, so that a row of the image planes is fetched into one L2 (plus the bands' halos), not eight
+    // (the launch is one-dimensional: 8 x ceil(tiles / 8) workgroups)
+    const int gx = (g.W1 + XT - 1) / XT, total = gx * ((g.H + TY - 1) / TY);
+    const int chunk = (total + 7) >> 3, tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tile >= total) return;
+    const int tbx = tile % gx, tby = tile / gx;
     const int xa = tbx * XT, ya = tby * TY;
     const size_t plane = (size_t)g.W * g.H;
     uint32_t* ring = s_ring + (size_t)wv * WIN * XT * 64 + lane;
@@ -366,23 +374,6 @@ __device__ __forceinline__ void cost_tile(const uint32_t* __restrict__ PL, const
                     *(uint32_t*)(C + ((size_t)y * g.W1 + x1) * g.Dp + 2 * dpl) = pad ? MAXC2 : acc[j];
             }
         }
-    }
-}
-
-// XCD-aware tile order: consecutive workgroups go to the 8 XCDs round-robin, each with an L2 of its own -- every XCD gets a
-// contiguous band of tile rows, so that a row of the image planes is fetched into one L2 (plus the bands' halos), not eight.
-// The grid is 8 x n workgroups (n <= ceil(tiles / 8)); workgroup b walks the tiles (b & 7) * chunk + (b >> 3) + i * n of its XCD.
-template <int XT, int SW2>
-__global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR,
-                                                        SgbmGeom g, int TY, int16_t* __restrict__ C)
-{
-    extern __shared__ uint32_t s_ring[];  // [waves][WIN][XT][64] + the staging rows
-    const int gx = (g.W1 + XT - 1) / XT, total = gx * ((g.H + TY - 1) / TY);
-    const int chunk = (total + 7) >> 3, per_xcd = (int)(gridDim.x >> 3);
-    for (int k = (int)(blockIdx.x >> 3); k < chunk; k += per_xcd) {
-        const int tile = (int)(blockIdx.x & 7) * chunk + k;
-        if (tile >= total) break;
-        cost_tile<XT, SW2>(PL, PR, g, TY, C, s_ring, tile % gx, tile / gx);
     }
 }
 
@@ -1399,10 +1390,9 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
                            ctx->planesL, ctx->planesR, ctx->ccl_size, ctx->sw_ctl, ctx->sw_ctl_words);
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
         const int TY = ctx->tune_sweep_ty;
-        static const int cost_wgs8 = getenv("VO_COST_WGS8") ? atoi(getenv("VO_COST_WGS8")) : (1 << 20);   // experiment: workgroups per XCD
         const int nw = bx / 64;
 #define LAUNCH_SWEEP(XT, SW)                                                                                                   \
-    hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(8 * min(div_up(div_up(g.W1, XT) * div_up(h, TY), 8), cost_wgs8)), dim3(bx), \
+    hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(8 * div_up(div_up(g.W1, XT) * div_up(h, TY), 8)), dim3(bx),            \
                        (size_t)nw * ((2 * SW + 1) * XT * 64 + 12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->planesL, ctx->planesR, g, TY, ctx->C)
         if (dbg & 4) {
         } else
