@@ -233,7 +233,7 @@ int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double
  * positions (xy_b_out: `cap` x 2 floats, may be NULL) travel with the record.  Results are those of vo_mono_pair, bit for bit.
  * A slot read by an open ticket may be refilled at any time: the refill is ordered behind the ticket's work on the device.
  * VO_E_STATE when every alternate is open. */
-#define VO_NUM_MONO_ASYNC 3
+#define VO_NUM_MONO_ASYNC 5
 /* 1 when the look-ahead work into `slot` (vo_prefetch_*) has finished or none is pending, 0 while it still runs; never blocks */
 int vo_slot_ready(vo_ctx* ctx, int slot, int* ready_out);
 int vo_mono_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ratio, const double* K4, int iters, float thr, uint32_t seed,

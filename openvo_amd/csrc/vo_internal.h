@@ -195,7 +195,7 @@ struct vo_ctx {
     } pose_alt[N_POSE_ALT];
     int pose_next = 0;
     // asynchronous monocular pair steps (vo_mono_pair_begin / _end): match scratch + RANSAC workspace + stream + pinned record each
-    static const int N_MONO_ALT = 3;
+    static const int N_MONO_ALT = VO_NUM_MONO_ASYNC;
     struct MonoAlt {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;

@@ -20,36 +20,46 @@ import numpy as np
 from . import _native
 
 
+def _det3(M):
+    return (M[0, 0] * (M[1, 1] * M[2, 2] - M[1, 2] * M[2, 1]) - M[0, 1] * (M[1, 0] * M[2, 2] - M[1, 2] * M[2, 0])
+            + M[0, 2] * (M[1, 0] * M[2, 1] - M[1, 1] * M[2, 0]))
+
+
+_W = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+
+
 def decompose_essential(E):
     """The two rotations and the translation direction of an essential matrix (Hartley & Zisserman 9.6.2)."""
     U, _, Vt = np.linalg.svd(E)
-    if np.linalg.det(U) < 0:
+    if _det3(U) < 0:
         U = -U
-    if np.linalg.det(Vt) < 0:
+    if _det3(Vt) < 0:
         Vt = -Vt
-    W = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
-    return U @ W @ Vt, U @ W.T @ Vt, U[:, 2]
+    UW = U @ _W
+    return UW @ Vt, (U @ _W.T) @ Vt, U[:, 2]
 
 
 def recover_pose(E, x1, x2):
     """(R, t) with x2 ~ R x1 + t for normalised image points x1, x2 (n x 2): the candidate that puts most points
-    in front of both cameras."""
+    in front of both cameras; ties go to the first of (R1, t), (R1, -t), (R2, t), (R2, -t).  Both depths change sign
+    exactly when t does, so each rotation is evaluated once (with +t) and serves two candidates."""
     R1, R2, t = decompose_essential(E)
-    best, arg = -1, None
-    h1 = np.c_[x1, np.ones(len(x1))]
-    h2 = np.c_[x2, np.ones(len(x2))]
-    for R in (R1, R2):
-        for tt in (t, -t):
-            # depth of each point in camera 1 from the two rays: z1 (R h1) + t = z2 h2
-            a = h1 @ R.T
-            num = np.cross(h2, np.broadcast_to(tt, h2.shape))
-            den = np.cross(a, h2)
-            z1 = np.sum(num * den, 1) / np.maximum(np.sum(den * den, 1), 1e-300)
-            z2 = np.sum((z1[:, None] * a + tt) * h2, 1) / np.sum(h2 * h2, 1)
-            good = int(np.sum((z1 > 0) & (z2 > 0)))
-            if good > best:
-                best, arg = good, (R, tt)
-    return arg[0], arg[1], best
+    n = len(x1)
+    h1 = np.empty((n, 3)); h1[:, :2] = x1; h1[:, 2] = 1.0
+    Rs = np.stack([R1, R2])                                       # (2, 3, 3)
+    # depth of each point in camera 1 from the two rays: z1 (R h1) + t = z2 h2   (h2 = (x2, 1))
+    a = np.matmul(h1[None], Rs.transpose(0, 2, 1))               # (2, n, 3): R h1
+    hx, hy = x2[None, :, 0], x2[None, :, 1]
+    ax, ay, az = a[..., 0], a[..., 1], a[..., 2]
+    nx, ny, nz = hy * t[2] - t[1], t[0] - hx * t[2], hx * t[1] - hy * t[0]         # h2 x t
+    dx, dy, dz = ay - az * hy, az * hx - ax, ax * hy - ay * hx                     # (R h1) x h2
+    z1 = (nx * dx + ny * dy + nz * dz) / np.maximum(dx * dx + dy * dy + dz * dz, 1e-300)
+    z2 = (z1 * ax + t[0]) * hx + (z1 * ay + t[1]) * hy + (z1 * az + t[2])          # x |h2|^2 > 0: only its sign counts
+    plus = np.count_nonzero((z1 > 0) & (z2 > 0), axis=1)
+    minus = np.count_nonzero((z1 < 0) & (z2 < 0), axis=1)
+    good = (int(plus[0]), int(minus[0]), int(plus[1]), int(minus[1]))
+    k = good.index(max(good))
+    return (R1, R2)[k >> 1], (t if (k & 1) == 0 else -t), good[k]
 
 
 class MonoOdometer:
@@ -69,17 +79,17 @@ class MonoOdometer:
         self.ransac_iters, self.ransac_threshold, self.min_inliers, self.seed = int(ransac_iters), float(ransac_threshold), int(min_inliers), int(seed)
         self._c_T_w = np.eye(4)          # world (= first frame) expressed in the current camera frame, like StereoOdometer
         from concurrent.futures import ThreadPoolExecutor
-        self._pool, self._pending = ThreadPoolExecutor(1), None    # the last accepted pair's pose recovery runs beside the next pair's GPU work
+        self._pool, self._pending = ThreadPoolExecutor(1), []      # accepted pairs' pose recoveries run beside the next pairs' GPU work
         self.last = None                 # dict of the last pair step
         self.skip_cause = ""
         # staged streams run ahead: the ORB extraction of the next frames is enqueued on look-ahead engines
         # (vo_prefetch_staged_mono) while the main stream matches and scores the current pair
-        self.lookahead = int(os.environ.get("VO_MONO_LOOKAHEAD", "4"))
+        self.lookahead = int(os.environ.get("VO_MONO_LOOKAHEAD", "5"))
         # ... and so do the pair steps: frame k + 1's step against frame k is begun (vo_mono_pair_begin, own stream) before
         # frame k's own step has been collected, on the assumption that k will be accepted as the next reference.  The
         # chains of up to `speculate` later pairs overlap the current one's; a rejected frame voids them (they are collected
         # and dropped, the pair is run again against the reference that stayed).  Results do not depend on any of this.
-        self.speculate = max(0, min(int(os.environ.get("VO_MONO_SPECULATE", "2")), _native.VO_NUM_MONO_ASYNC - 1))
+        self.speculate = max(0, min(int(os.environ.get("VO_MONO_SPECULATE", "3")), _native.VO_NUM_MONO_ASYNC - 1))
         self._free = list(range(10))     # frame slots this odometer uses
         self._ahead = {}                 # staged index -> slot with its extraction in flight
         self._count = {}                 # slot -> keypoint count, once the host has collected it
@@ -209,20 +219,23 @@ class MonoOdometer:
         fx, fy, cx, cy = self.K4
         # E -> (R, t) is host arithmetic on a few hundred inliers: it runs on a worker thread while this thread is inside
         # the next frame's native calls (which release the GIL); c_T_w / current_pose() collect it
-        self._flush()
-        self._pending = (self._pool.submit(recover_pose, r["E"].copy(), (xa - [cx, cy]) / [fx, fy], (xb - [cx, cy]) / [fx, fy]), float(scale))
+        while len(self._pending) >= 8:   # (bounded: a reader of c_T_w never finds more than a few poses to wait for)
+            self._collect_one()
+        self._pending.append((self._pool.submit(recover_pose, r["E"].copy(), (xa - [cx, cy]) / [fx, fy], (xb - [cx, cy]) / [fx, fy]), float(scale)))
         self._free.append(prev)          # the new frame becomes the reference; the old slot is reused
         self._ref = (cur, xy_cur)
         return True
 
+    def _collect_one(self):
+        fut, scale = self._pending.pop(0)
+        R, t, _ = fut.result()
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, t / max(np.linalg.norm(t), 1e-300) * scale
+        self._c_T_w = T @ self._c_T_w
+
     def _flush(self):
-        if self._pending is not None:
-            fut, scale = self._pending
-            self._pending = None
-            R, t, _ = fut.result()
-            T = np.eye(4)
-            T[:3, :3], T[:3, 3] = R, t / max(np.linalg.norm(t), 1e-300) * scale
-            self._c_T_w = T @ self._c_T_w
+        while self._pending:
+            self._collect_one()
 
     @property
     def c_T_w(self):

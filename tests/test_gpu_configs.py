@@ -312,7 +312,7 @@ def test_mono_lookahead_gives_the_same_chain():
 
 
 def test_mono_pair_begin_end_equals_the_synchronous_step_and_tickets_end_in_any_order():
-    """vo_mono_pair_begin / _end: three pairs in flight on three alternates give, bit for bit, what vo_mono_pair gives one at
+    """vo_mono_pair_begin / _end: three pairs in flight on alternates of their own give, bit for bit, what vo_mono_pair gives one at
     a time; tickets may be collected in any order; a fourth begin is refused while all are open; a slot read by an open
     ticket may be refilled (the refill is ordered behind the ticket on the device)."""
     c = Corridor("C5")
@@ -326,8 +326,11 @@ def test_mono_pair_begin_end_equals_the_synchronous_step_and_tickets_end_in_any_
     xy = [ctx.download_keypoints_xy(s) for s in range(4)]
     tickets = [ctx.mono_pair_begin(a, a + 1, 0.8, K4, 1500, 1.0, 4321, want_matches=True, solver=5) for a in range(3)]
     assert sorted(tickets) == [0, 1, 2]
-    with pytest.raises(Exception):
+    extra = [ctx.mono_pair_begin(0, 1, 0.8, K4, 1500, 1.0, 4321, want_matches=False, solver=5) for _ in range(_native.VO_NUM_MONO_ASYNC - 3)]
+    with pytest.raises(Exception):                                     # every alternate is open
         ctx.mono_pair_begin(0, 1, 0.8, K4, 1500, 1.0, 4321, want_matches=True, solver=5)
+    for t in extra:
+        assert ctx.mono_pair_end(t)["best_count"] == want[0]["best_count"]
     ctx.upload_mono(0, frames[4])                                      # slot 0 is still being read by the first ticket
     for a in (1, 2, 0):
         got = ctx.mono_pair_end(tickets[a], want_matches=True)
