@@ -181,8 +181,10 @@ int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int min_matc
                  double outlier_thr, int32_t* counts4, int32_t* rc2, double* T1_12, double* T2_12);
 /* the same step split in two so that the host does not wait for it: _begin enqueues it on a stream of its
  * own (ordered behind the producers of both slots) and returns a ticket, _end waits for that ticket and
- * delivers what vo_pose_pair would have.  At most three tickets may be open.  Lets the pose of pair (i, i+1)
- * run while the caller still handles pair (i-1, i). */
+ * delivers what vo_pose_pair would have.  At most VO_NUM_POSE_ASYNC tickets may be open (each has scratch and a pinned record
+ * of its own; they share three streams; tickets may end in any order).  Lets the pose steps of the pairs whose frames are already on the
+ * device run while the caller still handles an earlier pair. */
+#define VO_NUM_POSE_ASYNC 8
 int vo_pose_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ratio, int min_matches, double rigidity_thr,
                        double outlier_thr, int* ticket_out);
 int vo_pose_pair_end(vo_ctx* ctx, int ticket, int32_t* counts4, int32_t* rc2, double* T1_12, double* T2_12);

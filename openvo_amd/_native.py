@@ -16,6 +16,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 VO_NUM_SLOTS = 28
 VO_NUM_HOST_STAGE = 20
 VO_NUM_MONO_ASYNC = 5
+VO_NUM_POSE_ASYNC = 8
 SCHED_DIAG, SCHED_DIAG_RAGGED, SCHED_UNFUSED = 1, 2, 3
 T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose")
 

@@ -1361,7 +1361,9 @@ static int pose_alt_prepare(vo_ctx* ctx, int k)
     vo_ctx::PoseAlt& p = ctx->pose_alt[k];
     if (p.ready) return VO_OK;
     const size_t cap = (size_t)ctx->kp_cap;
-    VO_HIP(ctx, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    hipStream_t& shared = ctx->pose_streams[k % vo_ctx::N_POSE_STREAMS];
+    if (!shared) VO_HIP(ctx, hipStreamCreateWithFlags(&shared, hipStreamNonBlocking));
+    p.stream = shared;                            // (not owned by the alternate)
     VO_HIP(ctx, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     VO_HIP(ctx, hipHostMalloc(&p.result, 1024, hipHostMallocDefault));
     VO_HIP(ctx, hipMalloc((void**)&p.m_idx, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.m_dist, cap * 8 + 256));
@@ -1385,8 +1387,11 @@ void pose_alt_free(vo_ctx* ctx)
         for (void* q : ps) if (q) (void)hipFree(q);
         if (p.result) (void)hipHostFree(p.result);
         if (p.done) (void)hipEventDestroy(p.done);
-        if (p.stream) (void)hipStreamDestroy(p.stream);
         p = vo_ctx::PoseAlt();
+    }
+    for (hipStream_t& st : ctx->pose_streams) {
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
     }
 }
 
@@ -1397,9 +1402,11 @@ extern "C" int vo_pose_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
     int rc = pose_check(ctx, slot_a, slot_b);
     if (rc) return rc;
     VO_HIP(ctx, hipSetDevice(ctx->device));
-    const int k = ctx->pose_next;
+    int k = -1;                                   // the first free alternate from the round-robin position on (tickets need not end in order)
+    for (int i = 0; i < vo_ctx::N_POSE_ALT && k < 0; i++)
+        if (!ctx->pose_alt[(ctx->pose_next + i) % vo_ctx::N_POSE_ALT].busy) k = (ctx->pose_next + i) % vo_ctx::N_POSE_ALT;
+    if (k < 0) return vo_fail(ctx, VO_E_STATE, "vo_pose_pair_begin: every asynchronous pose step is still open (end one first)");
     vo_ctx::PoseAlt& p = ctx->pose_alt[k];
-    if (p.busy) return vo_fail(ctx, VO_E_STATE, "vo_pose_pair_begin: every asynchronous pose step is still open (end one first)");
     if ((rc = pose_alt_prepare(ctx, k))) return rc;
     FrameSlot& a = ctx->slots[slot_a];
     FrameSlot& b = ctx->slots[slot_b];

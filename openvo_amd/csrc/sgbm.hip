@@ -1304,6 +1304,10 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
                 else hipLaunchKernelGGL((k_sgbm_pair<NP, false>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->C, Swe, ck, vol, g, pp, ctx->dump);
             }
             VO_CHECK_LAUNCH(ctx);
+            if (ctx->cur_engine >= 0 && ctx->ws_alt[ctx->cur_engine].mid) {
+                vo_ctx::SgbmWs& a = ctx->ws_alt[ctx->cur_engine];
+                if (hipEventRecord(a.mid, ctx->stream) == hipSuccess) a.mid_valid = true;
+            }
             if (hh && (rc = launch_diag<NP, true, false>(ctx, g, Swe, Srev, ctlA))) return rc;
         }
         {

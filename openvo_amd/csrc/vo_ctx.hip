@@ -204,6 +204,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     }
     if (const char* e27 = getenv("VO_DIAG_WGS")) ctx->tune_diag_wgs = atoi(e27);
     if (const char* e26 = getenv("VO_DIAG_DEBUG")) ctx->tune_diag_dbg = atoi(e26);
+    if (const char* e27 = getenv("VO_STAGGER")) ctx->tune_stagger = atoi(e27);
     if (const char* e25 = getenv("VO_DIAG_WAVES")) ctx->tune_diag_nwc = atoi(e25) == 15 ? 15 : 7;
 #ifdef VO_TEST_HOOKS
     if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);   // test-only build (libvo355_hooks.so)
@@ -251,6 +252,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         orb_ws_free(a.orb);
         if (a.pinned) (void)hipHostFree(a.pinned);
         if (a.h2d_done) (void)hipEventDestroy(a.h2d_done);
+        if (a.mid) (void)hipEventDestroy(a.mid);
         if (ctx->la_stream[k]) (void)hipStreamDestroy(ctx->la_stream[k]);
     }
     for (vo_ctx::HostStage& hs : ctx->host_stage) {
@@ -543,6 +545,7 @@ static int engine_prepare(vo_ctx* ctx, int engine)
 {
     if (!ctx->la_stream[engine]) {
         VO_HIP(ctx, hipStreamCreateWithFlags(&ctx->la_stream[engine], hipStreamNonBlocking));
+        VO_HIP(ctx, hipEventCreateWithFlags(&ctx->ws_alt[engine].mid, hipEventDisableTiming));
         VO_HIP(ctx, hipMalloc((void**)&ctx->la_stage[engine], ctx->stage_bytes * 2 + 256));
         if (orb_ws_alloc(ctx, ctx->ws_alt[engine].orb)) return vo_fail(ctx, VO_E_HIP, "hipMalloc failed (look-ahead ORB workspace)");
     }
@@ -631,6 +634,11 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
     f.w = w; f.h = h; f.has_kp = false; f.n_kp = 0; f.kp_pending = false;
     {
         EngineScope on_engine(ctx, engine);          // ctx->stream / staging / SGBM + ORB workspaces are the engine's in here
+        const int stagger = ctx->tune_stagger >= 0 ? ctx->tune_stagger : ctx->n_engines / 2;
+        if (stagger > 0 && stagger < ctx->n_engines) {
+            vo_ctx::SgbmWs& p = ctx->ws_alt[(engine - stagger + ctx->n_engines) % ctx->n_engines];
+            if (p.mid_valid) (void)hipStreamWaitEvent(ctx->stream, p.mid, 0);
+        }
         rc = slot_before_overwrite(ctx, f);
         if (!rc) {
             StageTimer t(ctx, VO_T_UPLOAD);

@@ -75,6 +75,11 @@ struct vo_ctx {
     static const int MAX_ENGINES = 24;
     hipStream_t la_stream[MAX_ENGINES] = {};
     int cur_engine = -1;
+    // VO_STAGGER = K: a pair's early stages (cost volume, W + E) start only after those of the pair K places before it have finished
+    // (an event wait on the engine's stream; default: half the engines, 0 = off).  Keeps the pairs in flight spread over the stages
+    // -- at most K of them in the early ones -- instead of all in the same one after a cold start: +2.5 % on a 20-pair burst,
+    // +1.5 % in the steady state with 16 engines (K = 7..8; K <= 4 costs throughput, K >= 12 changes nothing).
+    int tune_stagger = -1;
     uint8_t* la_stage[MAX_ENGINES] = {};
     hipEvent_t sgbm_done = nullptr;  // end of the latest SGBM run in the CURRENT workspace (any stream)
     bool sgbm_done_valid = false;
@@ -94,6 +99,8 @@ struct vo_ctx {
         uint8_t* pinned = nullptr;       // host staging of vo_prefetch_pair (two raw images)
         hipEvent_t h2d_done = nullptr;   // the copies out of `pinned` have finished
         bool h2d_valid = false;
+        hipEvent_t mid = nullptr;        // the early stages (cost volume, W + E) of the engine's latest pair have finished
+        bool mid_valid = false;
     } ws_alt[MAX_ENGINES];           // [0] unused (engine 0 uses the main workspace)
     // ORB behind the look-ahead SGBM (vo_set_lookahead_orb): nfeatures, mask_mode, min/max disp16
     bool la_orb = false;
@@ -180,7 +187,13 @@ struct vo_ctx {
     size_t clique_ws_bytes = 0;
     // asynchronous pose steps (vo_pose_pair_begin / _end): two alternates of the match / pose scratch above,
     // each with its own stream, a pinned result record and a completion event
-    static const int N_POSE_ALT = 3;
+    static const int N_POSE_ALT = VO_NUM_POSE_ASYNC;
+    // the alternates' steps run on THREE streams (alternate k on stream k % 3): a context must stay at about twenty HIP streams
+    // (16 engines + main + these) -- beyond that the hardware queues are time-sliced in ~10 ms quanta and a pair's diagonal
+    // sweep stalls behind a descheduled neighbour (measured: 23 streams -> 200-1000 pairs/s).  Steps that share a stream run
+    // back to back without the host in between; their scratch and records are separate.
+    static const int N_POSE_STREAMS = 3;
+    hipStream_t pose_streams[N_POSE_STREAMS] = {};
     struct PoseAlt {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;

@@ -6,6 +6,8 @@ test, 3-D lookup, rigid-body clique filter, Umeyama fit) runs in libvo355 on the
 stays in Python is the sequential bookkeeping of `update` -- it decides which frames pair up,
 so it follows the reference decision for decision (pinned by tests/golden/g5_state_machine.json).
 """
+import os
+
 import numpy as np
 
 from . import _native
@@ -50,6 +52,8 @@ class StereoOdometer:
         self.skip_cause = ""
         self._specs = {}             # (slot key a, slot key b, params) -> ticket of a pose step started ahead of time
         self._next_hint = ()         # SubmittedPairs expected by the next update() calls (set by run())
+        self._ahead_counts = {}      # (slot, generation), ORB arguments -> keypoint count of a look-ahead pair already collected
+        self.pose_ahead = max(0, min(int(os.environ.get("VO_POSE_AHEAD", "6")), _native.VO_NUM_POSE_ASYNC - 1))
 
     # ------------------------------------------------------------------------------------------
     def feature_mask(self, disparity):
@@ -140,35 +144,46 @@ class StereoOdometer:
                 del self._specs[key]
 
     def _start_next_pose(self):
-        """The frame just accepted is the new `current`.  If the pairs that will come next are already on the
-        device (look-ahead / submitted ahead), start their matching + pose steps now on streams of their own:
-        (current, next) and -- expecting `next` to be accepted as well -- (next, next+1), so that two frame
-        periods hide the latency of the short kernel chain.  Purely an ordering change: _pair_fused looks a
-        step up by its slots and parameters and computes on the spot when the guess was wrong."""
+        """The frame just accepted is the new `current`.  The pairs that will come next may already be on the device
+        (look-ahead / submitted ahead): for as many of them as have FINISHED their disparity and keypoints (never waiting for
+        one), start the matching + pose step now on a stream of its own -- (current, next), and, expecting every frame to be
+        accepted, (next, next+1), ... up to `pose_ahead` steps.  In the steady state that is the next pair or none; when
+        results arrive in a burst (a cold start: every pair in flight finishes at about the same time) the short kernel
+        chains of many pairs run side by side instead of one after the other behind the host.  Purely an ordering change:
+        _pair_fused looks a step up by its slots and parameters and computes on the spot when the guess was wrong."""
         if not self._fused_ok() or self.orb.last_slot_args is None:
             return self._drop_specs()
         kps = self.current_kps
         if not self._on_device(kps, self.current_desc, self.current_3d):
             return self._drop_specs()
-        nxt = [h.slot for h in self._next_hint] if self._next_hint else self.stereo.next_lookahead_slots(2)
+        depth = self.pose_ahead
+        nxt = [h.slot for h in self._next_hint] if self._next_hint else self.stereo.next_lookahead_slots(depth)
         chain, counts = [kps.frame.slot], [len(kps)]
-        for s in nxt[:2]:
-            if s is None:
+        for s in nxt[:depth]:
+            if s is None or not self._ctx.slot_ready(s):
                 break
             chain.append(s)
-            counts.append(self._ctx.orb_slot_count(s, *self.orb.last_slot_args))   # waits for that pair's look-ahead work
+            key = (self.stereo.slot_key(s), self.orb.last_slot_args)
+            if key not in self._ahead_counts:
+                if len(self._ahead_counts) > 64:
+                    self._ahead_counts.clear()
+                self._ahead_counts[key] = self._ctx.orb_slot_count(s, *self.orb.last_slot_args)   # (finished: only collects the count)
+            counts.append(self._ahead_counts[key])
         params = self._pose_params()
         sk = self.stereo.slot_key       # slot + generation: a slot refilled with another pair never matches
-        wanted = [(sk(chain[j]), sk(chain[j + 1]), params) for j in range(len(chain) - 1)
-                  if 0 < counts[j] <= 3800 and counts[j + 1] >= max(2, self.min_matches)]
+        wanted = []
+        for j in range(len(chain) - 1):
+            if not (0 < counts[j] <= 3800 and counts[j + 1] >= max(2, self.min_matches)):
+                break                    # (a frame that will be rejected: what lies behind it pairs with another reference)
+            wanted.append((sk(chain[j]), sk(chain[j + 1]), params))
         self._drop_specs(keep=wanted)
         from ._native import VoError
         for key in wanted:
-            if key not in self._specs:
+            if key not in self._specs and len(self._specs) < _native.VO_NUM_POSE_ASYNC:
                 try:
                     self._specs[key] = self._ctx.pose_pair_begin(key[0][0], key[1][0], *params)
                 except VoError:
-                    pass                     # nothing started: update() computes the step when it gets there
+                    break                    # nothing started: update() computes the step when it gets there
 
     def run(self, pairs, depth=None):
         """Feed an iterable of host (left, right) pairs through update(), keeping up to `depth` pairs
@@ -227,7 +242,7 @@ class StereoOdometer:
                 if not queue:
                     return
                 head = queue.popleft()
-                self._next_hint = tuple(queue)[:2]
+                self._next_hint = tuple(queue)[:self.pose_ahead]
                 try:
                     yield self.update(head, None)
                 finally:
