@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev L, const u
 // ---------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------
-// Enqueue one extraction on ctx->stream (scratch: ctx->orb).  The keypoint count lands in the slot's
+// Enqueue one extraction on ctx->stream (scratch: (*ctx->orbws)).  The keypoint count lands in the slot's
 // pinned word; orb_finish() reads it once the stream (or the slot's `ready` event) has been waited for.
 static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img_stride, int w, int h, int nfeatures, int mask_mode,
                        const int16_t* d_disp16, int disp_stride, int min_d16, int max_d16, const uint8_t* d_mask, int mask_stride)
@@ -673,24 +673,24 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
     const int with_mask = mask_mode != 0;
     StageTimer t(ctx, VO_T_ORB);
     hipLaunchKernelGGL(k_orb_level0, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_img, img_stride, w, h, mask_mode,
-                       d_disp16, disp_stride, min_d16, max_d16, d_mask, mask_stride, ctx->orb.pyr_img, ctx->orb.pyr_mask, ctx->orb.counters);
+                       d_disp16, disp_stride, min_d16, max_d16, d_mask, mask_stride, ctx->orbws->pyr_img, ctx->orbws->pyr_mask, ctx->orbws->counters);
     for (int l = 1; l < NL; l++)
         hipLaunchKernelGGL(k_orb_resize, dim3(div_up(Lh->l[l].w, 256), Lh->l[l].h), dim3(256), 0, ctx->stream, dL, l, ctx->rs_ofs,
-                           ctx->rs_coef, ctx->orb.pyr_img, ctx->orb.pyr_mask, with_mask);
+                           ctx->rs_coef, ctx->orbws->pyr_img, ctx->orbws->pyr_mask, with_mask);
     hipLaunchKernelGGL(k_orb_fast_nms, dim3(div_up(w - 2 * EDGE, 64), div_up(h - 2 * EDGE, 16), NL), dim3(256), 0, ctx->stream, dL,
-                       ctx->orb.pyr_img, ctx->orb.pyr_mask, with_mask, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.counters);
+                       ctx->orbws->pyr_img, ctx->orbws->pyr_mask, with_mask, ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->counters);
     // after the select, cand_* hold the per-level final lists; candB_* are scratch
-    hipLaunchKernelGGL(k_orb_select_fast, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.candA_pos,
-                       ctx->orb.counters);
-    hipLaunchKernelGGL(k_orb_harris, dim3(nfeatures > 2000 ? 256 : 32, NL), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.candA_pos,
-                       ctx->orb.candA_resp, ctx->orb.counters);
-    hipLaunchKernelGGL(k_orb_select_harris, dim3(NL), dim3(1024), (size_t)ORB_RANK_LDS * 4, ctx->stream, dL, ctx->orb.candA_pos, ctx->orb.candA_resp,
-                       ctx->orb.cand_pos, ctx->orb.cand_resp, ctx->orb.candB_pos, ctx->orb.candB_resp, ctx->orb.counters);
-    hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->orb.pyr_img, ctx->orb.cand_pos,
-                       ctx->orb.cand_resp, ctx->orb.counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, fs->kp_angle,
+    hipLaunchKernelGGL(k_orb_select_fast, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->candA_pos,
+                       ctx->orbws->counters);
+    hipLaunchKernelGGL(k_orb_harris, dim3(nfeatures > 2000 ? 256 : 32, NL), dim3(256), 0, ctx->stream, dL, ctx->orbws->pyr_img, ctx->orbws->candA_pos,
+                       ctx->orbws->candA_resp, ctx->orbws->counters);
+    hipLaunchKernelGGL(k_orb_select_harris, dim3(NL), dim3(1024), (size_t)ORB_RANK_LDS * 4, ctx->stream, dL, ctx->orbws->candA_pos, ctx->orbws->candA_resp,
+                       ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->candB_pos, ctx->orbws->candB_resp, ctx->orbws->counters);
+    hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->orbws->pyr_img, ctx->orbws->cand_pos,
+                       ctx->orbws->cand_resp, ctx->orbws->counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, fs->kp_angle,
                        fs->desc);
     VO_CHECK_LAUNCH(ctx);
-    VO_HIP(ctx, hipMemcpyAsync(fs->n_kp_host, ctx->orb.counters + CNT_TOTAL, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(fs->n_kp_host, ctx->orbws->counters + CNT_TOTAL, 4, hipMemcpyDeviceToHost, ctx->stream));
     return VO_OK;
 }
 

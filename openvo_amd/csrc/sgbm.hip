@@ -1201,11 +1201,11 @@ static PathPlan make_plan(const SgbmGeom& g, int mode)
 // the current workspace's S holds at least `vols` volumes (grown once; the default covers the fused schedule)
 static int ensure_S(vo_ctx* ctx, int vols)
 {
-    if (ctx->S_vols >= vols) return VO_OK;
-    if (ctx->S) (void)hipFree(ctx->S);
-    ctx->S = nullptr; ctx->S_vols = 0;
-    VO_HIP(ctx, hipMalloc((void**)&ctx->S, ctx->vol_cells * sizeof(int16_t) * vols + 256));
-    ctx->S_vols = vols;
+    if (ctx->ws->S_vols >= vols) return VO_OK;
+    if (ctx->ws->S) (void)hipFree(ctx->ws->S);
+    ctx->ws->S = nullptr; ctx->ws->S_vols = 0;
+    VO_HIP(ctx, hipMalloc((void**)&ctx->ws->S, ctx->vol_cells * sizeof(int16_t) * vols + 256));
+    ctx->ws->S_vols = vols;
     return VO_OK;
 }
 
@@ -1221,17 +1221,17 @@ static int launch_diag_k(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int
     // boundary granules of this workspace: [strip][H + 1 rows][NP][64 lanes] x 8 bytes, allocated (and cleared: tags start at
     // 1, no stale granule may match) when first needed or outgrown
     const size_t need = (size_t)jobs.nstrips * (g.H + 1) * 64 * NP * sizeof(uint64_t);
-    if (need > ctx->sw_bnd_bytes) {
-        if (ctx->sw_bnd) (void)hipFree(ctx->sw_bnd);
-        ctx->sw_bnd = nullptr; ctx->sw_bnd_bytes = 0;
-        VO_HIP(ctx, hipMalloc((void**)&ctx->sw_bnd, need + 256));
-        ctx->sw_bnd_bytes = need;
-        VO_HIP(ctx, hipMemsetAsync(ctx->sw_bnd, 0, need, ctx->stream));
+    if (need > ctx->ws->sw_bnd_bytes) {
+        if (ctx->ws->sw_bnd) (void)hipFree(ctx->ws->sw_bnd);
+        ctx->ws->sw_bnd = nullptr; ctx->ws->sw_bnd_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->ws->sw_bnd, need + 256));
+        ctx->ws->sw_bnd_bytes = need;
+        VO_HIP(ctx, hipMemsetAsync(ctx->ws->sw_bnd, 0, need, ctx->stream));
     }
     DiagJob& j = jobs.j[0];
-    j.C = ctx->C; j.in1 = in1; j.sout = sout; j.bnd = ctx->sw_bnd; j.aux0 = ctx->ccl_label; j.aux1 = ctx->ccl_runlen;
-    j.tag = ++ctx->sw_tag;
-    if (j.tag == 0) j.tag = ++ctx->sw_tag;
+    j.C = ctx->ws->C; j.in1 = in1; j.sout = sout; j.bnd = ctx->ws->sw_bnd; j.aux0 = ctx->ws->ccl_label; j.aux1 = ctx->ws->ccl_runlen;
+    j.tag = ++ctx->ws->sw_tag;
+    if (j.tag == 0) j.tag = ++ctx->ws->sw_tag;
     j.sink = ctx->max_w * ctx->max_h;          // every pixel array is allocated with 256 spare bytes
     j.dbg = ctx->tune_diag_dbg;
     const size_t lds = (size_t)DG_RING * 2 * CW * g.Dp * 2 + (WTA ? (size_t)NWC * 4 * 2 * g.Dp * 2 : 0) + 64 * 4;
@@ -1280,18 +1280,18 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
     int rc;
     if (g.ur < 100) {
         if ((rc = ensure_S(ctx, 3))) return rc;
-        int16_t* const Swe = ctx->S;
-        int16_t* const Srev = ctx->S + vol;
-        int16_t* const ck = ctx->S + 2 * vol;
-        int* const ctlA = ctx->sw_ctl;
-        int* const ctlB = ctx->sw_ctl + ctx->sw_ctl_words / 2;
+        int16_t* const Swe = ctx->ws->S;
+        int16_t* const Srev = ctx->ws->S + vol;
+        int16_t* const ck = ctx->ws->S + 2 * vol;
+        int* const ctlA = ctx->ws->sw_ctl;
+        int* const ctlB = ctx->ws->sw_ctl + ctx->sw_ctl_words / 2;
         {
             StageTimer t(ctx, VO_T_SGBM_AGG);
             if (ctx->tune_diag_dbg & 8) {
             } else if (g.W1 % 8 == 0 && g.W1 >= 16) {
                 const int nw = div_up(g.H, 4);
-                if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, Swe, ck, g, ctx->dump);
-                else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->C, Swe, ck, g, ctx->dump);
+                if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->ws->C, Swe, ck, g, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->ws->C, Swe, ck, g, ctx->dump);
             } else {
                 PathPlan pp = plan;                                  // the W / E pair alone: one line per image row
                 pp.n_dirs = 1;
@@ -1300,8 +1300,8 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
                 for (int k = 0; k < VO_MAX_DIRS; k++) pp.first_wave[k + 1] = div_up(g.H, 4);
                 for (int k = 1; k < VO_MAX_DIRS; k++) pp.sx[k] = pp.sy[k] = pp.nlines[k] = 0;
                 const int nwp = pp.first_wave[1];
-                if (pad) hipLaunchKernelGGL((k_sgbm_pair<NP, true>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->C, Swe, ck, vol, g, pp, ctx->dump);
-                else hipLaunchKernelGGL((k_sgbm_pair<NP, false>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->C, Swe, ck, vol, g, pp, ctx->dump);
+                if (pad) hipLaunchKernelGGL((k_sgbm_pair<NP, true>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->ws->C, Swe, ck, vol, g, pp, ctx->dump);
+                else hipLaunchKernelGGL((k_sgbm_pair<NP, false>), dim3(div_up(nwp, 4)), dim3(256), 0, ctx->stream, ctx->ws->C, Swe, ck, vol, g, pp, ctx->dump);
             }
             VO_CHECK_LAUNCH(ctx);
             if (ctx->cur_engine >= 0 && ctx->ws_alt[ctx->cur_engine].mid) {
@@ -1313,7 +1313,7 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
         {
             StageTimer t(ctx, VO_T_SGBM_WTA);
             if (!(ctx->tune_diag_dbg & 16) && (rc = launch_diag<NP, false, true>(ctx, g, hh ? Srev : Swe, nullptr, hh ? ctlB : ctlA))) return rc;
-            hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ccl_label, ctx->ccl_runlen, g, ctx->disp_tmp, ctx->ccl_size);
+            hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ws->ccl_label, ctx->ws->ccl_runlen, g, ctx->ws->disp_tmp, ctx->ws->ccl_size);
             VO_CHECK_LAUNCH(ctx);
         }
         ctx->last_paths = 3;
@@ -1325,16 +1325,16 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
         StageTimer t(ctx, VO_T_SGBM_AGG);
         const int nwaves = plan.first_wave[plan.n_dirs];
         constexpr int PF = NP <= 4 ? 8 : 4;
-        if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, PF, true>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump);
-        else hipLaunchKernelGGL((k_sgbm_paths<NP, PF, false>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->C, ctx->S, vol, g, plan, ctx->dump);
+        if (pad) hipLaunchKernelGGL((k_sgbm_paths<NP, PF, true>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->ws->C, ctx->ws->S, vol, g, plan, ctx->dump);
+        else hipLaunchKernelGGL((k_sgbm_paths<NP, PF, false>), dim3(div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->ws->C, ctx->ws->S, vol, g, plan, ctx->dump);
         VO_CHECK_LAUNCH(ctx);
     }
     {
         StageTimer t(ctx, VO_T_SGBM_WTA);
         const size_t sh = (size_t)16 * g.Dp * sizeof(int16_t);   // one row of S per 16-lane group
         const long long npix = (long long)g.W1 * g.H;
-        hipLaunchKernelGGL((k_sgbm_wta<NP>), dim3((unsigned)((npix + 15) / 16)), dim3(256), sh, ctx->stream, ctx->S, vol, plan.n_dirs,
-                           g, ctx->disp_tmp, ctx->ccl_size);
+        hipLaunchKernelGGL((k_sgbm_wta<NP>), dim3((unsigned)((npix + 15) / 16)), dim3(256), sh, ctx->stream, ctx->ws->S, vol, plan.n_dirs,
+                           g, ctx->ws->disp_tmp, ctx->ws->ccl_size);
         VO_CHECK_LAUNCH(ctx);
     }
     ctx->last_paths = plan.n_dirs;
@@ -1349,11 +1349,11 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
 // stream -- has finished.  An event chain orders them on the device without blocking the host.
 int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp)
 {
-    if (ctx->sgbm_done_valid) VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sgbm_done, 0));
+    if (ctx->ws->done_valid) VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ws->done, 0));
     int rc = sgbm_run_impl(ctx, dL, dR, w, h, d_disp);
-    if (ctx->sgbm_done) {
-        VO_HIP(ctx, hipEventRecord(ctx->sgbm_done, ctx->stream));
-        ctx->sgbm_done_valid = true;
+    if (ctx->ws->done) {
+        VO_HIP(ctx, hipEventRecord(ctx->ws->done, ctx->stream));
+        ctx->ws->done_valid = true;
     }
     return rc;
 }
@@ -1391,13 +1391,13 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
         StageTimer t(ctx, VO_T_SGBM_COST);
         const int dbg = ctx->tune_diag_dbg;          // development only (VO_DIAG_DEBUG): 4 / 8 / 16 / 32 skip the cost / W+E / diagonal / post stage
         hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
-                           ctx->planesL, ctx->planesR, ctx->ccl_size, ctx->sw_ctl, ctx->sw_ctl_words);
+                           ctx->ws->planesL, ctx->ws->planesR, ctx->ws->ccl_size, ctx->ws->sw_ctl, ctx->sw_ctl_words);
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
         const int TY = ctx->tune_sweep_ty;
         const int nw = bx / 64;
 #define LAUNCH_SWEEP(XT, SW)                                                                                                   \
     hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(8 * div_up(div_up(g.W1, XT) * div_up(h, TY), 8)), dim3(bx),            \
-                       (size_t)nw * ((2 * SW + 1) * XT * 64 + 12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->planesL, ctx->planesR, g, TY, ctx->C)
+                       (size_t)nw * ((2 * SW + 1) * XT * 64 + 12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->ws->planesL, ctx->ws->planesR, g, TY, ctx->ws->C)
         if (dbg & 4) {
         } else
         switch (g.SW2) {
@@ -1408,7 +1408,7 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
             case 4: LAUNCH_SWEEP(8, 4); break;
             case 5: LAUNCH_SWEEP(8, 5); break;
             default:
-                hipLaunchKernelGGL(k_sgbm_cost_generic, dim3(g.W1, h), dim3(bx), 0, ctx->stream, ctx->planesL, ctx->planesR, g, ctx->C);
+                hipLaunchKernelGGL(k_sgbm_cost_generic, dim3(g.W1, h), dim3(bx), 0, ctx->stream, ctx->ws->planesL, ctx->ws->planesR, g, ctx->ws->C);
         }
 #undef LAUNCH_SWEEP
         VO_CHECK_LAUNCH(ctx);
@@ -1427,13 +1427,13 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
     if (rc) return rc;
     if (!(ctx->tune_diag_dbg & 32)) {
         StageTimer t(ctx, VO_T_SGBM_POST);
-        hipLaunchKernelGGL(k_lr_median3, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, ctx->disp_tmp, ctx->ccl_size, g, d_disp);
+        hipLaunchKernelGGL(k_lr_median3, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, ctx->ws->disp_tmp, ctx->ws->ccl_size, g, d_disp);
         if (e.speckleWindow > 0) {
             const int newVal = g.invalid16, maxDiff = 16 * e.speckleRange;
-            hipLaunchKernelGGL(k_ccl_rows, dim3(h), dim3(256), 0, ctx->stream, d_disp, w, newVal, maxDiff, ctx->ccl_label, ctx->ccl_runlen, ctx->ccl_size);
-            hipLaunchKernelGGL(k_ccl_vmerge, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ccl_label, ctx->ccl_runlen);
-            hipLaunchKernelGGL(k_ccl_sizes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ccl_label, ctx->ccl_runlen, ctx->ccl_size);
-            hipLaunchKernelGGL(k_ccl_apply, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_disp, n, newVal, e.speckleWindow, ctx->ccl_label, ctx->ccl_size);
+            hipLaunchKernelGGL(k_ccl_rows, dim3(h), dim3(256), 0, ctx->stream, d_disp, w, newVal, maxDiff, ctx->ws->ccl_label, ctx->ws->ccl_runlen, ctx->ws->ccl_size);
+            hipLaunchKernelGGL(k_ccl_vmerge, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_runlen);
+            hipLaunchKernelGGL(k_ccl_sizes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_runlen, ctx->ws->ccl_size);
+            hipLaunchKernelGGL(k_ccl_apply, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_disp, n, newVal, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_size);
         }
         VO_CHECK_LAUNCH(ctx);
     }

@@ -135,7 +135,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s)", prop.name, prop.gcnArchName);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
-    (void)hipEventCreateWithFlags(&ctx->sgbm_done, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&ctx->ws->done, hipEventDisableTiming);
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
 
@@ -152,17 +152,17 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     ctx->stage_bytes = npx * 3;
     DALLOC(ctx->stage_in, ctx->stage_bytes * 2);
     for (int c = 0; c < 2; c++) { DALLOC(ctx->map1[c], npx * 2); DALLOC(ctx->map2[c], npx); }
-    DALLOC(ctx->planesL, npx * 2); DALLOC(ctx->planesR, npx * 6);
+    DALLOC(ctx->ws->planesL, npx * 2); DALLOC(ctx->ws->planesR, npx * 6);
     ctx->vol_cells = npx * (size_t)((max_disp + 31) & ~31);
-    DALLOC(ctx->C, ctx->vol_cells);
+    DALLOC(ctx->ws->C, ctx->vol_cells);
     // aggregated volumes: L_W + L_E, MODE_HH's reverse-pass sum, checkpoints (grown on demand for uniquenessRatio >= 100)
-    ctx->S_vols = 3;
-    DALLOC(ctx->S, ctx->vol_cells * ctx->S_vols);
+    ctx->ws->S_vols = 3;
+    DALLOC(ctx->ws->S, ctx->vol_cells * ctx->ws->S_vols);
     ctx->sw_ctl_words = 2 * 2048;                        // two control blocks: {work items taken, sticky error, ...} + per-strip timeline
-    DALLOC(ctx->sw_ctl, ctx->sw_ctl_words);
-    VO_HIP(ctx, hipMemset(ctx->sw_ctl, 0, ctx->sw_ctl_words * sizeof(int)));
-    DALLOC(ctx->disp_tmp, npx); DALLOC(ctx->dump, 4096);
-    DALLOC(ctx->ccl_label, npx); DALLOC(ctx->ccl_size, npx); DALLOC(ctx->ccl_runlen, npx);
+    DALLOC(ctx->ws->sw_ctl, ctx->sw_ctl_words);
+    VO_HIP(ctx, hipMemset(ctx->ws->sw_ctl, 0, ctx->sw_ctl_words * sizeof(int)));
+    DALLOC(ctx->ws->disp_tmp, npx); DALLOC(ctx->dump, 4096);
+    DALLOC(ctx->ws->ccl_label, npx); DALLOC(ctx->ws->ccl_size, npx); DALLOC(ctx->ws->ccl_runlen, npx);
     // ORB: 8-level pyramid is < 3.2x the base image
     ctx->pyr_bytes = npx * 4;
     DALLOC(ctx->rs_ofs, (size_t)(max_w + max_h) * 2 * VO_ORB_LEVELS);
@@ -172,7 +172,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     // FAST candidates after NMS are never 8-adjacent: at most ceil(w/2)*ceil(h/2) per level
     ctx->cand_cap = (int)((size_t)((max_w + 1) / 2) * ((max_h + 1) / 2));
     // (summed over the 8 levels: < 3.2x that)
-    if (orb_ws_alloc(ctx, ctx->orb)) { g_create_err = "hipMalloc failed (ORB workspace)"; vo_destroy(ctx); return VO_E_HIP; }
+    if (orb_ws_alloc(ctx, (*ctx->orbws))) { g_create_err = "hipMalloc failed (ORB workspace)"; vo_destroy(ctx); return VO_E_HIP; }
     DALLOC(ctx->m_count, 64);
     DALLOC(ctx->host_mask_dev, npx);
     DALLOC(ctx->mq, (size_t)ctx->kp_cap * 32); DALLOC(ctx->mt, (size_t)ctx->kp_cap * 32);
@@ -231,19 +231,19 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         for (void* p : ps) if (p) (void)hipFree(p);
         if (f.ready) (void)hipEventDestroy(f.ready);
     }
-    void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->planesL, ctx->planesR,
-                   ctx->C, ctx->S, ctx->sw_bnd, ctx->sw_ctl, ctx->disp_tmp, ctx->dump, ctx->ccl_runlen, ctx->ccl_label, ctx->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
+    void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->ws->planesL, ctx->ws->planesR,
+                   ctx->ws->C, ctx->ws->S, ctx->ws->sw_bnd, ctx->ws->sw_ctl, ctx->ws->disp_tmp, ctx->dump, ctx->ws->ccl_runlen, ctx->ws->ccl_label, ctx->ws->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
                    ctx->m_idx, ctx->m_dist, ctx->pts_a, ctx->pts_b, ctx->st_a, ctx->st_b, ctx->xy_a, ctx->xy_b,
                    ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws, ctx->ransac_ws };
     for (void* p : ps) if (p) (void)hipFree(p);
-    orb_ws_free(ctx->orb);
+    orb_ws_free(*ctx->orbws);
     pose_alt_free(ctx);
     mono_alt_free(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->slot_words) (void)hipHostFree(ctx->slot_words);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->staged) (void)hipFree(ctx->staged);
-    if (ctx->sgbm_done) (void)hipEventDestroy(ctx->sgbm_done);
+    if (ctx->ws->done) (void)hipEventDestroy(ctx->ws->done);
     for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) {
         vo_ctx::SgbmWs& a = ctx->ws_alt[k];
         void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.sw_bnd, a.sw_ctl, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->la_stage[k] };
@@ -508,34 +508,28 @@ extern "C" int vo_load_staged_pair(vo_ctx* ctx, int slot, int index, int preproc
     return VO_OK;
 }
 
-// swap the main stream / staging (and for engines >= 1 the SGBM workspace) with a look-ahead engine's;
-// calling it twice restores the context
-static void engine_swap(vo_ctx* ctx, int engine)
-{
-    std::swap(ctx->stream, ctx->la_stream[engine]);
-    std::swap(ctx->stage_in, ctx->la_stage[engine]);
-    vo_ctx::SgbmWs& a = ctx->ws_alt[engine];
-    std::swap(ctx->orb, a.orb);   // every engine has its own ORB scratch
-    if (engine == 0) return;
-    std::swap(ctx->planesL, a.planesL); std::swap(ctx->planesR, a.planesR);
-    std::swap(ctx->C, a.C); std::swap(ctx->S, a.S); std::swap(ctx->S_vols, a.S_vols);
-    std::swap(ctx->sw_bnd, a.sw_bnd); std::swap(ctx->sw_bnd_bytes, a.sw_bnd_bytes); std::swap(ctx->sw_ctl, a.sw_ctl); std::swap(ctx->sw_tag, a.sw_tag);
-    std::swap(ctx->disp_tmp, a.disp_tmp);
-    std::swap(ctx->ccl_runlen, a.ccl_runlen); std::swap(ctx->ccl_label, a.ccl_label); std::swap(ctx->ccl_size, a.ccl_size);
-    std::swap(ctx->sgbm_done, a.done); std::swap(ctx->sgbm_done_valid, a.done_valid);
-}
-
-// Retargets the context at a look-ahead engine for the lifetime of the object.  Whatever path leaves the
-// scope -- a status funnelled through rc or an early return of a VO_HIP check added later -- the context
-// comes back un-crossed.
+// Retargets the context at a look-ahead engine for the lifetime of the object: its stream and staging buffer change places
+// with the main ones, `ws` / `orbws` point at the engine's SGBM workspace (engine 0: the main one) and ORB scratch.  No member
+// of any workspace is copied or swapped.  Whatever path leaves the scope -- a status funnelled through rc or an early return of
+// a VO_HIP check added later -- the context comes back pointing at its own.
 struct EngineScope {
     vo_ctx* ctx;
     int engine;
-    EngineScope(vo_ctx* c, int e) : ctx(c), engine(e) { engine_swap(ctx, engine); ctx->cur_engine = engine; }
+    EngineScope(vo_ctx* c, int e) : ctx(c), engine(e)
+    {
+        std::swap(ctx->stream, ctx->la_stream[engine]);
+        std::swap(ctx->stage_in, ctx->la_stage[engine]);
+        ctx->ws = engine == 0 ? &ctx->main_ws : &ctx->ws_alt[engine];
+        ctx->orbws = &ctx->ws_alt[engine].orb;
+        ctx->cur_engine = engine;
+    }
     ~EngineScope()
     {
         ctx->cur_engine = -1;
-        engine_swap(ctx, engine);
+        ctx->ws = &ctx->main_ws;
+        ctx->orbws = &ctx->main_ws.orb;
+        std::swap(ctx->stage_in, ctx->la_stage[engine]);
+        std::swap(ctx->stream, ctx->la_stream[engine]);
     }
     EngineScope(const EngineScope&) = delete;
     EngineScope& operator=(const EngineScope&) = delete;
@@ -1091,7 +1085,7 @@ extern "C" int vo_sgbm_sweep_status(vo_ctx* ctx, int* error_out)
     // word 1 of each control block of every workspace: set (and never cleared) when a wait inside a diagonal
     // sweep exceeded its poll limit
     int any = 0;
-    int* blocks[vo_ctx::MAX_ENGINES + 1] = { ctx->sw_ctl };
+    int* blocks[vo_ctx::MAX_ENGINES + 1] = { ctx->ws->sw_ctl };
     for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) blocks[k + 1] = ctx->ws_alt[k].sw_ctl;
     for (int* b : blocks) {
         if (!b) continue;
@@ -1125,7 +1119,7 @@ extern "C" int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemp
     const int64_t cap = (int64_t)ctx->vol_cells * 2;
     if (bytes <= 0 || bytes > cap) bytes = cap;
     bytes &= ~(int64_t)4095;
-    if (bytes <= 0 || !ctx->C || !ctx->S) return vo_fail(ctx, VO_E_STATE, "vo_measure_copy: no volumes to copy between");
+    if (bytes <= 0 || !ctx->ws->C || !ctx->ws->S) return vo_fail(ctx, VO_E_STATE, "vo_measure_copy: no volumes to copy between");
     VO_HIP(ctx, hipSetDevice(ctx->device));
     // the volumes belong to the main workspace (engine 0 uses it too): nothing of the pipeline may still be running
     for (int k = 0; k < vo_ctx::MAX_ENGINES; k++)
@@ -1137,8 +1131,8 @@ extern "C" int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemp
     const size_t n16 = (size_t)bytes / 16;
     const int blocks = 256 * 16;                           // 16 workgroups per CU, grid-stride
     auto launch = [&]() {
-        if (nontemporal) hipLaunchKernelGGL(k_copy_stream<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const copy_u32x4*)ctx->S, (copy_u32x4*)ctx->C, n16);
-        else hipLaunchKernelGGL(k_copy_stream<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const copy_u32x4*)ctx->S, (copy_u32x4*)ctx->C, n16);
+        if (nontemporal) hipLaunchKernelGGL(k_copy_stream<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const copy_u32x4*)ctx->ws->S, (copy_u32x4*)ctx->ws->C, n16);
+        else hipLaunchKernelGGL(k_copy_stream<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const copy_u32x4*)ctx->ws->S, (copy_u32x4*)ctx->ws->C, n16);
     };
     launch();                                               // warm-up (page tables, clocks)
     VO_HIP(ctx, hipEventRecord(e0, ctx->stream));
@@ -1163,7 +1157,7 @@ extern "C" int vo_sgbm_sweep_stats(vo_ctx* ctx, int block, int32_t* out, int n_w
     if (rc) return rc;
     const int half = ctx->sw_ctl_words / 2;
     if (n_words > half) n_words = half;
-    VO_HIP(ctx, hipMemcpy(out, ctx->sw_ctl + block * half, (size_t)n_words * sizeof(int32_t), hipMemcpyDeviceToHost));
+    VO_HIP(ctx, hipMemcpy(out, ctx->ws->sw_ctl + block * half, (size_t)n_words * sizeof(int32_t), hipMemcpyDeviceToHost));
     return VO_OK;
 }
 

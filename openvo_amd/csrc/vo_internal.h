@@ -81,8 +81,9 @@ struct vo_ctx {
     // +1.5 % in the steady state with 16 engines (K = 7..8; K <= 4 costs throughput, K >= 12 changes nothing).
     int tune_stagger = -1;
     uint8_t* la_stage[MAX_ENGINES] = {};
-    hipEvent_t sgbm_done = nullptr;  // end of the latest SGBM run in the CURRENT workspace (any stream)
-    bool sgbm_done_valid = false;
+    // One SGBM workspace: everything a disparity run writes.  The context owns one (`main_ws`: the main stream and look-ahead
+    // engine 0 use it) and one per further engine; `ws` / `orbws` name the workspace and the ORB scratch the code in sgbm.hip /
+    // orb.hip works in right now -- the main ones, or an engine's while that engine is being fed (EngineScope).
     struct SgbmWs {
         uint32_t *planesL = nullptr, *planesR = nullptr;
         int16_t *C = nullptr, *S = nullptr, *disp_tmp = nullptr;
@@ -92,7 +93,7 @@ struct vo_ctx {
         size_t sw_bnd_bytes = 0;
         int* sw_ctl = nullptr;
         uint32_t sw_tag = 0;
-        hipEvent_t done = nullptr;
+        hipEvent_t done = nullptr;       // end of the latest SGBM run in this workspace (any stream)
         bool done_valid = false;
         bool ready = false;
         OrbWs orb;
@@ -101,7 +102,10 @@ struct vo_ctx {
         bool h2d_valid = false;
         hipEvent_t mid = nullptr;        // the early stages (cost volume, W + E) of the engine's latest pair have finished
         bool mid_valid = false;
-    } ws_alt[MAX_ENGINES];           // [0] unused (engine 0 uses the main workspace)
+    } ws_alt[MAX_ENGINES];           // [0]: only its ORB scratch / staging / events are used (engine 0 works in main_ws)
+    SgbmWs main_ws;
+    SgbmWs* ws = &main_ws;
+    OrbWs* orbws = &main_ws.orb;
     // ORB behind the look-ahead SGBM (vo_set_lookahead_orb): nfeatures, mask_mode, min/max disp16
     bool la_orb = false;
     int la_orb_params[4] = {0, 0, 0, 0};
@@ -130,26 +134,16 @@ struct vo_ctx {
     uint8_t* stage_in = nullptr;   // raw upload (max_w*max_h*3)
     size_t stage_bytes = 0;
 
-    // SGBM workspace
-    uint32_t* planesL = nullptr;   // per pixel 2 x u32 (u,u0,u1 for both channels)
-    uint32_t* planesR = nullptr;   // per pixel 6 x u32 pair-packed (v,v0,v1 x 2 channels)
-    int16_t* C = nullptr;          // cost volume
-    int16_t* S = nullptr;          // aggregated volume
+    // SGBM workspace: see SgbmWs (ws->planesL: per pixel 2 x u32 (u,u0,u1 for both channels); ws->planesR: per pixel 6 x u32
+    // pair-packed (v,v0,v1 x 2 channels); ws->C: cost volume; ws->S: aggregated volumes (S_vols of them); ws->disp_tmp: WTA output
+    // before the LR check; ws->sw_bnd: boundary granules of the diagonal sweep (allocated on first use); ws->sw_ctl: its two control
+    // blocks {work items taken, sticky error, ..., per-strip timeline}; ws->sw_tag: launches so far in that workspace)
     size_t vol_cells = 0;
-    int S_vols = 0;                // path volumes allocated behind S
-    int16_t* disp_tmp = nullptr;   // WTA output before the LR check
     int16_t* dump = nullptr;       // sink for the stores of lanes past the end of their scan line
-    uint64_t* sw_bnd = nullptr;    // diagonal sweep: boundary granules handed from strip to strip (allocated on first use)
-    size_t sw_bnd_bytes = 0;
-    int* sw_ctl = nullptr;         // diagonal sweep: two control blocks {work items taken, sticky error, ..., per-strip timeline}
     int sw_ctl_words = 0;
-    uint32_t sw_tag = 0;           // launches so far in the current workspace (tag of its boundary granules)
     int tune_diag_wgs = 0;         // VO_DIAG_WGS (development): workgroups of one diagonal sweep (0 = one image row's worth of strips + 2)
     int tune_diag_dbg = 0;         // VO_DIAG_DEBUG (development): bit 0 / 1 = strips import / export nothing, 4 / 8 / 16 / 32 = skip the cost / W+E / diagonal / post stage
     int tune_diag_nwc = 7;         // VO_DIAG_WAVES: compute waves per strip workgroup (7 or 15) for Dp <= 128
-    int32_t* ccl_runlen = nullptr;
-    int32_t* ccl_label = nullptr;
-    int32_t* ccl_size = nullptr;
     int64_t last_cells = 0;
     int last_paths = 0;
     int last_schedule = 0;         // VO_SCHED_* of the latest run (vo_sgbm_last_schedule)
@@ -158,7 +152,6 @@ struct vo_ctx {
     OrbLevel lv[VO_ORB_LEVELS];
     int orb_w = 0, orb_h = 0;      // geometry the pyramid tables were built for
     size_t pyr_bytes = 0;
-    OrbWs orb;                     // pyramids (all levels), FAST scores, candidate lists, counters
     int32_t* rs_ofs = nullptr;     // resize tables (all levels): x then y offsets
     uint16_t* rs_coef = nullptr;
     int32_t* rs_meta = nullptr;    // per level: table offsets + min/max
