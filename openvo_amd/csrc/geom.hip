@@ -157,12 +157,12 @@ extern "C" int vo_points3d_at(vo_ctx* ctx, int slot, const float* xy, int n, flo
     for (int i = 0; i < n; i++)
         if (!(xy[2 * i] >= 0 && xy[2 * i + 1] >= 0 && (int)xy[2 * i] < cw && (int)xy[2 * i + 1] < chh))
             return vo_fail(ctx, VO_E_ARG, "keypoint %d (%g,%g) outside the %dx%d cropped image", i, xy[2 * i], xy[2 * i + 1], cw, chh);
-    int rc = xfer_h2d(ctx, ctx->xy_a, xy, (size_t)n * 8);
+    int rc = xfer_h2d(ctx, ctx->mw->xy_a, xy, (size_t)n * 8);
     if (rc) return rc;
-    rc = points3d_launch(ctx, f.disp16, f.w, f.h, ctx->xy_a, n, ctx->pts_a, ctx->st_a);
+    rc = points3d_launch(ctx, f.disp16, f.w, f.h, ctx->mw->xy_a, n, ctx->mw->pts_a, ctx->mw->st_a);
     if (rc) return rc;
-    rc = xfer_d2h(ctx, xyz_out, ctx->pts_a, (size_t)n * 12);
-    if (!rc) rc = xfer_d2h(ctx, status_out, ctx->st_a, (size_t)n);
+    rc = xfer_d2h(ctx, xyz_out, ctx->mw->pts_a, (size_t)n * 12);
+    if (!rc) rc = xfer_d2h(ctx, status_out, ctx->mw->st_a, (size_t)n);
     if (rc) return rc;
     return xfer_flush(ctx);
 }
@@ -190,13 +190,13 @@ extern "C" int vo_bilinear_at(vo_ctx* ctx, const float* img3d, int w, int h, con
     int rc = ensure_ws(ctx, &ctx->img3_ws, &ctx->img3_ws_bytes, (size_t)w * h * 12);
     if (rc) return rc;
     VO_HIP(ctx, hipMemcpyAsync(ctx->img3_ws, img3d, (size_t)w * h * 12, hipMemcpyHostToDevice, ctx->stream));
-    rc = xfer_h2d(ctx, ctx->xy_a, xy, (size_t)n * 8);
+    rc = xfer_h2d(ctx, ctx->mw->xy_a, xy, (size_t)n * 8);
     if (rc) return rc;
     TapImg tap{ ctx->img3_ws, w };
-    hipLaunchKernelGGL(k_bilinear_img, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, tap, w, h, ctx->xy_a, n, ctx->pts_a, ctx->st_a);
+    hipLaunchKernelGGL(k_bilinear_img, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, tap, w, h, ctx->mw->xy_a, n, ctx->mw->pts_a, ctx->mw->st_a);
     VO_CHECK_LAUNCH(ctx);
-    rc = xfer_d2h(ctx, out, ctx->pts_a, (size_t)n * 12);
-    if (!rc) rc = xfer_d2h(ctx, status_out, ctx->st_a, (size_t)n);
+    rc = xfer_d2h(ctx, out, ctx->mw->pts_a, (size_t)n * 12);
+    if (!rc) rc = xfer_d2h(ctx, status_out, ctx->mw->st_a, (size_t)n);
     if (rc) return rc;
     return xfer_flush(ctx);
 }
@@ -303,13 +303,13 @@ extern "C" int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio
     int rc;
     {
         StageTimer t(ctx, VO_T_MATCH);
-        rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->m_idx, ctx->m_dist);
+        rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->mw->m_idx, ctx->mw->m_dist);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(a.n_kp > 512 ? 1024 : 256), 0, ctx->stream, ctx->m_idx, ctx->m_dist, a.n_kp, ratio, a.kp_xy,
-                           b.kp_xy, ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, ctx->m_count);
+        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(a.n_kp > 512 ? 1024 : 256), 0, ctx->stream, ctx->mw->m_idx, ctx->mw->m_dist, a.n_kp, ratio, a.kp_xy,
+                           b.kp_xy, ctx->mw->mq_idx, ctx->mw->mt_idx, ctx->mw->xy_a, ctx->mw->xy_b, ctx->mw->m_count);
         VO_CHECK_LAUNCH(ctx);
         // 3-D lookups for every query slot position (n_kp upper bound); only the first M are meaningful
-        VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->m_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->mw->m_count, 4, hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     const int m = *(int32_t*)ctx->pinned;
@@ -317,20 +317,20 @@ extern "C" int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio
     if (m == 0) return VO_OK;
     {
         StageTimer t(ctx, VO_T_POSE);
-        rc = points3d_launch(ctx, a.disp16, a.w, a.h, ctx->xy_a, m, ctx->pts_a, ctx->st_a);
+        rc = points3d_launch(ctx, a.disp16, a.w, a.h, ctx->mw->xy_a, m, ctx->mw->pts_a, ctx->mw->st_a);
         if (rc) return rc;
-        rc = points3d_launch(ctx, b.disp16, b.w, b.h, ctx->xy_b, m, ctx->pts_b, ctx->st_b);
+        rc = points3d_launch(ctx, b.disp16, b.w, b.h, ctx->mw->xy_b, m, ctx->mw->pts_b, ctx->mw->st_b);
         if (rc) return rc;
     }
     if (m > cap && (q_idx || t_idx || pts_a || pts_b || status_a || status_b))
         return vo_fail(ctx, VO_E_CAP, "%d matches exceed output capacity %d", m, cap);
     rc = VO_OK;
-    if (q_idx && !rc) rc = xfer_d2h(ctx, q_idx, ctx->mq_idx, (size_t)m * 4);
-    if (t_idx && !rc) rc = xfer_d2h(ctx, t_idx, ctx->mt_idx, (size_t)m * 4);
-    if (pts_a && !rc) rc = xfer_d2h(ctx, pts_a, ctx->pts_a, (size_t)m * 12);
-    if (pts_b && !rc) rc = xfer_d2h(ctx, pts_b, ctx->pts_b, (size_t)m * 12);
-    if (status_a && !rc) rc = xfer_d2h(ctx, status_a, ctx->st_a, (size_t)m);
-    if (status_b && !rc) rc = xfer_d2h(ctx, status_b, ctx->st_b, (size_t)m);
+    if (q_idx && !rc) rc = xfer_d2h(ctx, q_idx, ctx->mw->mq_idx, (size_t)m * 4);
+    if (t_idx && !rc) rc = xfer_d2h(ctx, t_idx, ctx->mw->mt_idx, (size_t)m * 4);
+    if (pts_a && !rc) rc = xfer_d2h(ctx, pts_a, ctx->mw->pts_a, (size_t)m * 12);
+    if (pts_b && !rc) rc = xfer_d2h(ctx, pts_b, ctx->mw->pts_b, (size_t)m * 12);
+    if (status_a && !rc) rc = xfer_d2h(ctx, status_a, ctx->mw->st_a, (size_t)m);
+    if (status_b && !rc) rc = xfer_d2h(ctx, status_b, ctx->mw->st_b, (size_t)m);
     if (rc) return rc;
     return xfer_flush(ctx);
 }
@@ -498,11 +498,11 @@ extern "C" int vo_umeyama(vo_ctx* ctx, const float* src, const float* dst, int m
     if (m > ctx->kp_cap) return vo_fail(ctx, VO_E_CAP, "m=%d exceeds capacity %d", m, ctx->kp_cap);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     StageTimer t(ctx, VO_T_POSE);
-    int rc = xfer_h2d(ctx, ctx->pts_a, src, (size_t)m * 12);
-    if (!rc) rc = xfer_h2d(ctx, ctx->pts_b, dst, (size_t)m * 12);
+    int rc = xfer_h2d(ctx, ctx->mw->pts_a, src, (size_t)m * 12);
+    if (!rc) rc = xfer_h2d(ctx, ctx->mw->pts_b, dst, (size_t)m * 12);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_umeyama_sums, dim3(1), dim3(256), 0, ctx->stream, ctx->pts_a, ctx->pts_b, m, ctx->red);
-    hipLaunchKernelGGL(k_umeyama_cov, dim3(1), dim3(256), 0, ctx->stream, ctx->pts_a, ctx->pts_b, m, ctx->red);
+    hipLaunchKernelGGL(k_umeyama_sums, dim3(1), dim3(256), 0, ctx->stream, ctx->mw->pts_a, ctx->mw->pts_b, m, ctx->red);
+    hipLaunchKernelGGL(k_umeyama_cov, dim3(1), dim3(256), 0, ctx->stream, ctx->mw->pts_a, ctx->mw->pts_b, m, ctx->red);
     VO_CHECK_LAUNCH(ctx);
     VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->red, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = xfer_flush(ctx))) return rc;
@@ -620,24 +620,24 @@ extern "C" int vo_rigid_clique(vo_ctx* ctx, const float* prev, const float* cur,
     if (m > ctx->kp_cap || (size_t)m * 12 > 150 * 1024) return vo_fail(ctx, VO_E_CAP, "m=%d exceeds capacity", m);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     const size_t need = (size_t)m * m + (size_t)m * 4 * 3 + (size_t)m * 8 + 1024;
-    if (ctx->clique_ws_bytes < need) {
-        if (ctx->clique_ws) (void)hipFree(ctx->clique_ws);
-        ctx->clique_ws = nullptr; ctx->clique_ws_bytes = 0;
-        VO_HIP(ctx, hipMalloc((void**)&ctx->clique_ws, need));
-        ctx->clique_ws_bytes = need;
+    if (ctx->mw->clique_ws_bytes < need) {
+        if (ctx->mw->clique_ws) (void)hipFree(ctx->mw->clique_ws);
+        ctx->mw->clique_ws = nullptr; ctx->mw->clique_ws_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->mw->clique_ws, need));
+        ctx->mw->clique_ws_bytes = need;
     }
     StageTimer t(ctx, VO_T_POSE);
     // carve: mask(8m) | ncons(4m) | clique(4m) | compat(4m) | cons(m*m)
-    long long* d_mask = (long long*)ctx->clique_ws;
-    int* d_ncons = (int*)(ctx->clique_ws + (size_t)m * 8);
+    long long* d_mask = (long long*)ctx->mw->clique_ws;
+    int* d_ncons = (int*)(ctx->mw->clique_ws + (size_t)m * 8);
     int* d_clique = d_ncons + m;
     int* d_compat = d_clique + m;
     uint8_t* d_cons = (uint8_t*)(d_compat + m);
-    int rc = xfer_h2d(ctx, ctx->pts_a, prev, (size_t)m * 12);
-    if (!rc) rc = xfer_h2d(ctx, ctx->pts_b, cur, (size_t)m * 12);
+    int rc = xfer_h2d(ctx, ctx->mw->pts_a, prev, (size_t)m * 12);
+    if (!rc) rc = xfer_h2d(ctx, ctx->mw->pts_b, cur, (size_t)m * 12);
     if (rc) return rc;
     VO_HIP(ctx, hipMemsetAsync(d_ncons, 0, (size_t)m * 4, ctx->stream));
-    hipLaunchKernelGGL(k_rigid_cons, dim3(div_up(m, 256), m), dim3(256), 0, ctx->stream, ctx->pts_a, ctx->pts_b, m, (float)thr, d_cons, d_ncons);
+    hipLaunchKernelGGL(k_rigid_cons, dim3(div_up(m, 256), m), dim3(256), 0, ctx->stream, ctx->mw->pts_a, ctx->mw->pts_b, m, (float)thr, d_cons, d_ncons);
     hipLaunchKernelGGL(k_rigid_clique, dim3(1), dim3(64), (size_t)m * 12, ctx->stream, d_cons, d_ncons, m, d_mask);
     VO_CHECK_LAUNCH(ctx);
     if ((rc = xfer_d2h(ctx, mask_out, d_mask, (size_t)m * 8))) return rc;
@@ -1250,13 +1250,13 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
     // for kp_cap query keypoints, so the branch below (a device-wide synchronisation) is never taken on the hot path
     const int words = (nq + 63) / 64;
     const size_t need = pose_ws_bytes(nq);
-    if (ctx->clique_ws_bytes < need) {
-        if (ctx->clique_ws) { VO_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->clique_ws); }
-        ctx->clique_ws = nullptr; ctx->clique_ws_bytes = 0;
-        VO_HIP(ctx, hipMalloc((void**)&ctx->clique_ws, need));
-        ctx->clique_ws_bytes = need;
+    if (ctx->mw->clique_ws_bytes < need) {
+        if (ctx->mw->clique_ws) { VO_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->mw->clique_ws); }
+        ctx->mw->clique_ws = nullptr; ctx->mw->clique_ws_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->mw->clique_ws, need));
+        ctx->mw->clique_ws_bytes = need;
     }
-    uint8_t* wsp = ctx->clique_ws;
+    uint8_t* wsp = ctx->mw->clique_ws;
     PoseOut* d_out = (PoseOut*)wsp; wsp += 1024;
     int* d_flags = (int*)wsp; wsp += 256;
     unsigned long long* d_bits = (unsigned long long*)wsp; wsp += (size_t)nq * words * 8;
@@ -1268,11 +1268,11 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
     float* d_rb = (float*)wsp; wsp += (size_t)nq * 12;
     uint8_t* d_lanebytes = (uint8_t*)(((uintptr_t)wsp + 15) & ~(uintptr_t)15);
     int* d_sets = (int*)(d_lanebytes + (size_t)nq * 64);          // 4 x m_cap ints (only used beyond 3584 keypoints)
-    int* d_m = ctx->m_count;  // k_pose_prep writes the match count M here
+    int* d_m = ctx->mw->m_count;  // k_pose_prep writes the match count M here
     int rc;
     {
         StageTimer t(ctx, VO_T_MATCH);
-        rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->m_idx, ctx->m_dist);
+        rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->mw->m_idx, ctx->mw->m_dist);
         if (rc) return rc;
     }
     {
@@ -1281,12 +1281,12 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
         if (ctx->has_roi) { x0 = ctx->roi[0]; y0 = ctx->roi[1]; x1 = ctx->roi[2] < a.w ? ctx->roi[2] : a.w; y1 = ctx->roi[3] < a.h ? ctx->roi[3] : a.h; }
         TapDisp ta{ a.disp16, a.w, x0, y0, make_q(ctx->Q) };
         TapDisp tb{ b.disp16, b.w, x0, y0, make_q(ctx->Q) };
-        hipLaunchKernelGGL(k_pose_prep, dim3(1), dim3(256), 0, ctx->stream, ctx->m_idx, ctx->m_dist, a.n_kp, ratio, a.kp_xy, b.kp_xy,
-                           ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, d_m, d_out, d_flags, ta, tb, x1 - x0, y1 - y0, ctx->pts_a,
-                           ctx->pts_b, ctx->st_a, ctx->st_b, d_ncons);
+        hipLaunchKernelGGL(k_pose_prep, dim3(1), dim3(256), 0, ctx->stream, ctx->mw->m_idx, ctx->mw->m_dist, a.n_kp, ratio, a.kp_xy, b.kp_xy,
+                           ctx->mw->mq_idx, ctx->mw->mt_idx, ctx->mw->xy_a, ctx->mw->xy_b, d_m, d_out, d_flags, ta, tb, x1 - x0, y1 - y0, ctx->mw->pts_a,
+                           ctx->mw->pts_b, ctx->mw->st_a, ctx->mw->st_b, d_ncons);
         const int use_filter = rigidity_thr > 0;
         if (use_filter)
-            hipLaunchKernelGGL(k_pose_cons_bits, dim3(nq), dim3(64), 0, ctx->stream, ctx->pts_a, ctx->pts_b, d_m, (float)rigidity_thr,
+            hipLaunchKernelGGL(k_pose_cons_bits, dim3(nq), dim3(64), 0, ctx->stream, ctx->mw->pts_a, ctx->mw->pts_b, d_m, (float)rigidity_thr,
                                d_bits, words, d_ncons, d_lanebytes);
         // LDS: 4 int arrays of nq (rounded to even so the bit matrix stays 8-byte aligned) + bit matrix if <= 48 KB
         const int m_cap = (nq + 1) & ~1;
@@ -1295,7 +1295,7 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
         if ((size_t)m_cap * 16 + bits_cap > 56 * 1024) bits_cap = 0;
         const bool sets_global = (size_t)m_cap * 16 > 56 * 1024;      // > 3584 keypoints: the sets move to the workspace, LDS stays empty
         hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(1024), sets_global ? 0 : (size_t)m_cap * 16 + bits_cap, ctx->stream, d_bits, words, d_ncons, d_m,
-                           use_filter, ctx->pts_a, ctx->pts_b, d_qa, d_qb, m_cap, bits_cap, d_flags, outlier_thr, min_matches, d_errs,
+                           use_filter, ctx->mw->pts_a, ctx->mw->pts_b, d_qa, d_qb, m_cap, bits_cap, d_flags, outlier_thr, min_matches, d_errs,
                            d_ra, d_rb, d_out, d_lanebytes, sets_global ? d_sets : nullptr);
         VO_CHECK_LAUNCH(ctx);
         VO_HIP(ctx, hipMemcpyAsync(host_out, d_out, sizeof(PoseOut), hipMemcpyDeviceToHost, ctx->stream));
@@ -1344,17 +1344,24 @@ extern "C" int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, i
     return VO_OK;
 }
 
-// swap the match / pose scratch and the stream with alternate k; calling it twice restores the context
-static void pose_swap(vo_ctx* ctx, int k)
-{
-    vo_ctx::PoseAlt& p = ctx->pose_alt[k];
-    std::swap(ctx->stream, p.stream);
-    std::swap(ctx->m_idx, p.m_idx); std::swap(ctx->m_count, p.m_count); std::swap(ctx->m_dist, p.m_dist);
-    std::swap(ctx->mq_idx, p.mq_idx); std::swap(ctx->mt_idx, p.mt_idx);
-    std::swap(ctx->pts_a, p.pts_a); std::swap(ctx->pts_b, p.pts_b); std::swap(ctx->xy_a, p.xy_a); std::swap(ctx->xy_b, p.xy_b);
-    std::swap(ctx->st_a, p.st_a); std::swap(ctx->st_b, p.st_b);
-    std::swap(ctx->clique_ws, p.clique_ws); std::swap(ctx->clique_ws_bytes, p.clique_ws_bytes);
-}
+// The context works on alternate k's stream and in its match scratch for the lifetime of the object, whatever leaves the scope
+// (the stream handle changes places with the main one, `mw` is retargeted; no member of a workspace is copied)
+struct PoseScope {
+    vo_ctx* c;
+    int k;
+    PoseScope(vo_ctx* c_, int k_) : c(c_), k(k_)
+    {
+        std::swap(c->stream, c->pose_alt[k].stream);
+        c->mw = &c->pose_alt[k].mw;
+    }
+    ~PoseScope()
+    {
+        c->mw = &c->main_mw;
+        std::swap(c->stream, c->pose_alt[k].stream);
+    }
+    PoseScope(const PoseScope&) = delete;
+    PoseScope& operator=(const PoseScope&) = delete;
+};
 
 static int pose_alt_prepare(vo_ctx* ctx, int k)
 {
@@ -1366,14 +1373,14 @@ static int pose_alt_prepare(vo_ctx* ctx, int k)
     p.stream = shared;                            // (not owned by the alternate)
     VO_HIP(ctx, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     VO_HIP(ctx, hipHostMalloc(&p.result, 1024, hipHostMallocDefault));
-    VO_HIP(ctx, hipMalloc((void**)&p.m_idx, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.m_dist, cap * 8 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&p.m_count, 256));
-    VO_HIP(ctx, hipMalloc((void**)&p.mq_idx, cap * 4 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.mt_idx, cap * 4 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&p.pts_a, cap * 12 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.pts_b, cap * 12 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&p.xy_a, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.xy_b, cap * 8 + 256));
-    VO_HIP(ctx, hipMalloc((void**)&p.st_a, cap + 256)); VO_HIP(ctx, hipMalloc((void**)&p.st_b, cap + 256));
-    p.clique_ws_bytes = pose_ws_bytes(ctx->kp_cap);
-    VO_HIP(ctx, hipMalloc((void**)&p.clique_ws, p.clique_ws_bytes));
+    VO_HIP(ctx, hipMalloc((void**)&p.mw.m_idx, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.mw.m_dist, cap * 8 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.mw.m_count, 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.mw.mq_idx, cap * 4 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.mw.mt_idx, cap * 4 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.mw.pts_a, cap * 12 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.mw.pts_b, cap * 12 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.mw.xy_a, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.mw.xy_b, cap * 8 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.mw.st_a, cap + 256)); VO_HIP(ctx, hipMalloc((void**)&p.mw.st_b, cap + 256));
+    p.mw.clique_ws_bytes = pose_ws_bytes(ctx->kp_cap);
+    VO_HIP(ctx, hipMalloc((void**)&p.mw.clique_ws, p.mw.clique_ws_bytes));
     p.ready = true;
     return VO_OK;
 }
@@ -1383,7 +1390,7 @@ void pose_alt_free(vo_ctx* ctx)
     for (int k = 0; k < vo_ctx::N_POSE_ALT; k++) {
         vo_ctx::PoseAlt& p = ctx->pose_alt[k];
         if (p.stream) (void)hipStreamSynchronize(p.stream);
-        void* ps[] = { p.m_idx, p.m_dist, p.m_count, p.mq_idx, p.mt_idx, p.pts_a, p.pts_b, p.xy_a, p.xy_b, p.st_a, p.st_b, p.clique_ws };
+        void* ps[] = { p.mw.m_idx, p.mw.m_dist, p.mw.m_count, p.mw.mq_idx, p.mw.mt_idx, p.mw.pts_a, p.mw.pts_b, p.mw.xy_a, p.mw.xy_b, p.mw.st_a, p.mw.st_b, p.mw.clique_ws };
         for (void* q : ps) if (q) (void)hipFree(q);
         if (p.result) (void)hipHostFree(p.result);
         if (p.done) (void)hipEventDestroy(p.done);
@@ -1417,11 +1424,7 @@ extern "C" int vo_pose_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
     // (look-ahead engines) and behind the main stream's work on them
     VO_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     {
-        struct PoseScope {      // the context works on alternate k's stream and scratch inside this block, whatever leaves it
-            vo_ctx* c; int k;
-            PoseScope(vo_ctx* c_, int k_) : c(c_), k(k_) { pose_swap(c, k); }
-            ~PoseScope() { pose_swap(c, k); }
-        } on_alt(ctx, k);
+        PoseScope on_alt(ctx, k);
         hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev0, 0);
         if (e == hipSuccess && a.pending) e = hipStreamWaitEvent(ctx->stream, a.ready, 0);
         if (e == hipSuccess && b.pending) e = hipStreamWaitEvent(ctx->stream, b.ready, 0);

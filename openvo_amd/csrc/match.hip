@@ -72,10 +72,10 @@ extern "C" int vo_bf_knn2_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const u
     int rc = xfer_h2d(ctx, ctx->mq, q, (size_t)nq * 32);
     if (!rc && nt) rc = xfer_h2d(ctx, ctx->mt, t, (size_t)nt * 32);
     if (rc) return rc;
-    rc = match_knn2(ctx, ctx->mq, nq, ctx->mt, nt, ctx->m_idx, ctx->m_dist);
+    rc = match_knn2(ctx, ctx->mq, nq, ctx->mt, nt, ctx->mw->m_idx, ctx->mw->m_dist);
     if (rc) return rc;
-    rc = xfer_d2h(ctx, idx, ctx->m_idx, (size_t)nq * 8);
-    if (!rc) rc = xfer_d2h(ctx, dist, ctx->m_dist, (size_t)nq * 8);
+    rc = xfer_d2h(ctx, idx, ctx->mw->m_idx, (size_t)nq * 8);
+    if (!rc) rc = xfer_d2h(ctx, dist, ctx->mw->m_dist, (size_t)nq * 8);
     if (rc) return rc;
     return xfer_flush(ctx);
 }

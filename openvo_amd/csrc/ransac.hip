@@ -259,13 +259,13 @@ static int ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, i
     VO_HIP(ctx, hipSetDevice(ctx->device));
     // workspace: points (2 x n x 8 B), E (iters x 72 B), F (iters x 36 B), counts, mask, best
     const size_t need = (size_t)n * 16 + (size_t)iters * (72 + 36 + 4) + (size_t)n + 4096;
-    if (ctx->ransac_ws_bytes < need) {
-        if (ctx->ransac_ws) (void)hipFree(ctx->ransac_ws);
-        ctx->ransac_ws = nullptr; ctx->ransac_ws_bytes = 0;
-        VO_HIP(ctx, hipMalloc((void**)&ctx->ransac_ws, need));
-        ctx->ransac_ws_bytes = need;
+    if (ctx->mw->ransac_ws_bytes < need) {
+        if (ctx->mw->ransac_ws) (void)hipFree(ctx->mw->ransac_ws);
+        ctx->mw->ransac_ws = nullptr; ctx->mw->ransac_ws_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->mw->ransac_ws, need));
+        ctx->mw->ransac_ws_bytes = need;
     }
-    uint8_t* w = ctx->ransac_ws;
+    uint8_t* w = ctx->mw->ransac_ws;
     double* d_E = (double*)w; w += (size_t)iters * 72;
     float* d_p1 = (float*)w; w += (size_t)n * 8;
     float* d_p2 = (float*)w; w += (size_t)n * 8;
@@ -330,14 +330,14 @@ static int mono_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, c
     const int min_n = solver == 5 ? 6 : 8;
     const int nq = a.n_kp;
     const size_t need = (size_t)iters * (72 + 36 + 4) + (size_t)nq + 4096;
-    if (ctx->ransac_ws_bytes < need) {
+    if (ctx->mw->ransac_ws_bytes < need) {
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->ransac_ws) (void)hipFree(ctx->ransac_ws);
-        ctx->ransac_ws = nullptr; ctx->ransac_ws_bytes = 0;
-        VO_HIP(ctx, hipMalloc((void**)&ctx->ransac_ws, need));
-        ctx->ransac_ws_bytes = need;
+        if (ctx->mw->ransac_ws) (void)hipFree(ctx->mw->ransac_ws);
+        ctx->mw->ransac_ws = nullptr; ctx->mw->ransac_ws_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->mw->ransac_ws, need));
+        ctx->mw->ransac_ws_bytes = need;
     }
-    uint8_t* w = ctx->ransac_ws;
+    uint8_t* w = ctx->mw->ransac_ws;
     double* d_E = (double*)w; w += (size_t)iters * 72;
     float* d_F = (float*)w; w += (size_t)iters * 36;
     int32_t* d_counts = (int32_t*)w; w += (size_t)iters * 4;
@@ -347,9 +347,9 @@ static int mono_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, c
     int rc;
     {
         StageTimer t(ctx, VO_T_MATCH);
-        if ((rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->m_idx, ctx->m_dist))) return rc;
-        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(nq > 512 ? 1024 : 256), 0, ctx->stream, ctx->m_idx, ctx->m_dist, nq, ratio, a.kp_xy, b.kp_xy,
-                           ctx->mq_idx, ctx->mt_idx, ctx->xy_a, ctx->xy_b, ctx->m_count);
+        if ((rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->mw->m_idx, ctx->mw->m_dist))) return rc;
+        hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(nq > 512 ? 1024 : 256), 0, ctx->stream, ctx->mw->m_idx, ctx->mw->m_dist, nq, ratio, a.kp_xy, b.kp_xy,
+                           ctx->mw->mq_idx, ctx->mw->mt_idx, ctx->mw->xy_a, ctx->mw->xy_b, ctx->mw->m_count);
     }
     {
         StageTimer t(ctx, VO_T_POSE);
@@ -357,13 +357,13 @@ static int mono_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, c
         const float thr2 = thr * thr;
         if (solver == 5) {
             if (int rc5 = hyp5_prepare(ctx)) return rc5;
-            hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), FP_LDS_DOUBLES * sizeof(double), ctx->stream, ctx->xy_a, ctx->xy_b, nq, K, iters, seed, d_E, d_F, ctx->m_count);
+            hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), FP_LDS_DOUBLES * sizeof(double), ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, K, iters, seed, d_E, d_F, ctx->mw->m_count);
         }
         else
-            hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, K, iters, seed, d_E, d_F, ctx->m_count);
-        hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, iters, thr2, d_counts, ctx->m_count, min_n);
+            hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, K, iters, seed, d_E, d_F, ctx->mw->m_count);
+        hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, d_F, iters, thr2, d_counts, ctx->mw->m_count, min_n);
         hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(1024), 0, ctx->stream, d_counts, iters, o.d_best);
-        hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, ctx->xy_a, ctx->xy_b, nq, d_F, o.d_best, thr2, o.d_mask, ctx->m_count, min_n);
+        hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, d_F, o.d_best, thr2, o.d_mask, ctx->mw->m_count, min_n);
         hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, ctx->stream, d_E, o.d_best, o.d_E9);
         VO_CHECK_LAUNCH(ctx);
     }
@@ -402,12 +402,12 @@ extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, c
     MonoDev o;
     if ((rc = mono_enqueue(ctx, a, b, ratio, K4v, iters, thr, seed, solver, o))) return rc;
     int32_t* h = (int32_t*)ctx->pinned;         // [0] M, [1..2] best, then E9 at byte 64
-    VO_HIP(ctx, hipMemcpyAsync(h, ctx->m_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(h, ctx->mw->m_count, 4, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(ctx, hipMemcpyAsync(h + 1, o.d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(ctx, hipMemcpyAsync((uint8_t*)ctx->pinned + 64, o.d_E9, 72, hipMemcpyDeviceToHost, ctx->stream));
     if (mask_out && (rc = xfer_d2h(ctx, mask_out, o.d_mask, (size_t)nq))) return rc;
-    if (q_idx && (rc = xfer_d2h(ctx, q_idx, ctx->mq_idx, (size_t)nq * 4))) return rc;
-    if (t_idx && (rc = xfer_d2h(ctx, t_idx, ctx->mt_idx, (size_t)nq * 4))) return rc;
+    if (q_idx && (rc = xfer_d2h(ctx, q_idx, ctx->mw->mq_idx, (size_t)nq * 4))) return rc;
+    if (t_idx && (rc = xfer_d2h(ctx, t_idx, ctx->mw->mt_idx, (size_t)nq * 4))) return rc;
     if ((rc = xfer_flush(ctx))) return rc;       // the one synchronisation
     counts3[0] = h[0]; counts3[1] = h[1]; counts3[2] = h[0] >= min_n ? h[2] : 0;
     memcpy(E9_out, (uint8_t*)ctx->pinned + 64, 72);
@@ -421,20 +421,28 @@ extern "C" int vo_mono_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, c
 // before it collects this one's.  Results land in the alternate's pinned record; vo_mono_pair_end waits for its event only.
 static const size_t MONO_HDR = 4096;             // record: [0] M, [1..2] best, E9 at byte 64; arrays from MONO_HDR on
 
-static void mono_swap(vo_ctx* ctx, int k)
-{
-    vo_ctx::MonoAlt& p = ctx->mono_alt[k];
-    std::swap(ctx->stream, p.stream);
-    std::swap(ctx->m_idx, p.m_idx); std::swap(ctx->m_count, p.m_count); std::swap(ctx->m_dist, p.m_dist);
-    std::swap(ctx->mq_idx, p.mq_idx); std::swap(ctx->mt_idx, p.mt_idx);
-    std::swap(ctx->xy_a, p.xy_a); std::swap(ctx->xy_b, p.xy_b);
-    std::swap(ctx->ransac_ws, p.ransac_ws); std::swap(ctx->ransac_ws_bytes, p.ransac_ws_bytes);
-}
+// the context works on alternate k's stream and in its match / RANSAC scratch for the lifetime of the object
+struct MonoScope {
+    vo_ctx* c;
+    int k;
+    MonoScope(vo_ctx* c_, int k_) : c(c_), k(k_)
+    {
+        std::swap(c->stream, c->mono_alt[k].stream);
+        c->mw = &c->mono_alt[k].mw;
+    }
+    ~MonoScope()
+    {
+        c->mw = &c->main_mw;
+        std::swap(c->stream, c->mono_alt[k].stream);
+    }
+    MonoScope(const MonoScope&) = delete;
+    MonoScope& operator=(const MonoScope&) = delete;
+};
 
 static void mono_alt_release(vo_ctx::MonoAlt& p)
 {
     if (p.stream) (void)hipStreamSynchronize(p.stream);
-    void* ps[] = { p.m_idx, p.m_dist, p.m_count, p.mq_idx, p.mt_idx, p.xy_a, p.xy_b, p.ransac_ws };
+    void* ps[] = { p.mw.m_idx, p.mw.m_dist, p.mw.m_count, p.mw.mq_idx, p.mw.mt_idx, p.mw.xy_a, p.mw.xy_b, p.mw.ransac_ws };
     for (void* q : ps) if (q) (void)hipFree(q);
     if (p.result) (void)hipHostFree(p.result);
     if (p.done) (void)hipEventDestroy(p.done);
@@ -451,7 +459,7 @@ static int mono_alt_prepare(vo_ctx* ctx, int k)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p.done, hipEventDisableTiming);
     p.result_bytes = MONO_HDR + cap * (1 + 4 + 4 + 8) + 64;
     if (e == hipSuccess) e = hipHostMalloc((void**)&p.result, p.result_bytes, hipHostMallocDefault);
-    void** ps[] = { (void**)&p.m_idx, (void**)&p.m_dist, (void**)&p.m_count, (void**)&p.mq_idx, (void**)&p.mt_idx, (void**)&p.xy_a, (void**)&p.xy_b };
+    void** ps[] = { (void**)&p.mw.m_idx, (void**)&p.mw.m_dist, (void**)&p.mw.m_count, (void**)&p.mw.mq_idx, (void**)&p.mw.mt_idx, (void**)&p.mw.xy_a, (void**)&p.mw.xy_b };
     const size_t sz[] = { cap * 8, cap * 8, 256, cap * 4, cap * 4, cap * 8, cap * 8 };
     for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]) && e == hipSuccess; i++) e = hipMalloc(ps[i], sz[i] + 256);
     if (e != hipSuccess) {
@@ -488,11 +496,7 @@ extern "C" int vo_mono_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
     // behind the main stream's work on them
     VO_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     {
-        struct MonoScope {      // the context works on alternate k's stream and scratch inside this block, whatever leaves it
-            vo_ctx* c; int k;
-            MonoScope(vo_ctx* c_, int k_) : c(c_), k(k_) { mono_swap(c, k); }
-            ~MonoScope() { mono_swap(c, k); }
-        } on_alt(ctx, k);
+        MonoScope on_alt(ctx, k);
         hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev0, 0);
         if (e == hipSuccess && a.pending) e = hipStreamWaitEvent(ctx->stream, a.ready, 0);
         if (e == hipSuccess && b.pending) e = hipStreamWaitEvent(ctx->stream, b.ready, 0);
@@ -502,15 +506,15 @@ extern "C" int vo_mono_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
             rc = mono_enqueue(ctx, a, b, ratio, K4v, iters, thr, seed, solver, o);
             uint8_t* r = p.result;
             const size_t nq = (size_t)a.n_kp, nb = (size_t)b.n_kp;
-            if (!rc) e = hipMemcpyAsync(r, ctx->m_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (!rc) e = hipMemcpyAsync(r, ctx->mw->m_count, 4, hipMemcpyDeviceToHost, ctx->stream);
             if (!rc && e == hipSuccess) e = hipMemcpyAsync(r + 4, o.d_best, 8, hipMemcpyDeviceToHost, ctx->stream);
             if (!rc && e == hipSuccess) e = hipMemcpyAsync(r + 64, o.d_E9, 72, hipMemcpyDeviceToHost, ctx->stream);
             if (!rc && p.want) {
                 uint8_t* q = r + MONO_HDR;
                 const size_t cap = (size_t)ctx->kp_cap;
                 if (e == hipSuccess) e = hipMemcpyAsync(q, o.d_mask, nq, hipMemcpyDeviceToHost, ctx->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(q + cap, ctx->mq_idx, nq * 4, hipMemcpyDeviceToHost, ctx->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(q + cap * 5, ctx->mt_idx, nq * 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(q + cap, ctx->mw->mq_idx, nq * 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(q + cap * 5, ctx->mw->mt_idx, nq * 4, hipMemcpyDeviceToHost, ctx->stream);
                 if (e == hipSuccess && nb) e = hipMemcpyAsync(q + cap * 9, b.kp_xy, nb * 8, hipMemcpyDeviceToHost, ctx->stream);
             }
             if (!rc && e != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
@@ -839,13 +843,13 @@ extern "C" int vo_ransac_pnp(vo_ctx* ctx, const float* pts3d, const float* pts2d
     VO_HIP(ctx, hipSetDevice(ctx->device));
     // workspace: Rt (iters x 96 B), points (n x 12 B + n x 8 B), P (iters x 48 B), counts, best, mask
     const size_t need = (size_t)n * 24 + (size_t)iters * (96 + 48 + 4) + (size_t)n + 4096;
-    if (ctx->ransac_ws_bytes < need) {
-        if (ctx->ransac_ws) (void)hipFree(ctx->ransac_ws);
-        ctx->ransac_ws = nullptr; ctx->ransac_ws_bytes = 0;
-        VO_HIP(ctx, hipMalloc((void**)&ctx->ransac_ws, need));
-        ctx->ransac_ws_bytes = need;
+    if (ctx->mw->ransac_ws_bytes < need) {
+        if (ctx->mw->ransac_ws) (void)hipFree(ctx->mw->ransac_ws);
+        ctx->mw->ransac_ws = nullptr; ctx->mw->ransac_ws_bytes = 0;
+        VO_HIP(ctx, hipMalloc((void**)&ctx->mw->ransac_ws, need));
+        ctx->mw->ransac_ws_bytes = need;
     }
-    uint8_t* w = ctx->ransac_ws;
+    uint8_t* w = ctx->mw->ransac_ws;
     double* d_Rt = (double*)w; w += (size_t)iters * 96;
     float* d_uv = (float*)w; w += (size_t)n * 8;
     float* d_X = (float*)w; w += (size_t)n * 12 + 8;

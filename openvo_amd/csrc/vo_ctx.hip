@@ -173,17 +173,17 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     ctx->cand_cap = (int)((size_t)((max_w + 1) / 2) * ((max_h + 1) / 2));
     // (summed over the 8 levels: < 3.2x that)
     if (orb_ws_alloc(ctx, (*ctx->orbws))) { g_create_err = "hipMalloc failed (ORB workspace)"; vo_destroy(ctx); return VO_E_HIP; }
-    DALLOC(ctx->m_count, 64);
+    DALLOC(ctx->mw->m_count, 64);
     DALLOC(ctx->host_mask_dev, npx);
     DALLOC(ctx->mq, (size_t)ctx->kp_cap * 32); DALLOC(ctx->mt, (size_t)ctx->kp_cap * 32);
-    DALLOC(ctx->m_idx, (size_t)ctx->kp_cap * 2); DALLOC(ctx->m_dist, (size_t)ctx->kp_cap * 2);
-    DALLOC(ctx->pts_a, (size_t)ctx->kp_cap * 3); DALLOC(ctx->pts_b, (size_t)ctx->kp_cap * 3);
-    DALLOC(ctx->st_a, ctx->kp_cap); DALLOC(ctx->st_b, ctx->kp_cap);
-    DALLOC(ctx->xy_a, (size_t)ctx->kp_cap * 2); DALLOC(ctx->xy_b, (size_t)ctx->kp_cap * 2);
-    DALLOC(ctx->mq_idx, ctx->kp_cap); DALLOC(ctx->mt_idx, ctx->kp_cap);
+    DALLOC(ctx->mw->m_idx, (size_t)ctx->kp_cap * 2); DALLOC(ctx->mw->m_dist, (size_t)ctx->kp_cap * 2);
+    DALLOC(ctx->mw->pts_a, (size_t)ctx->kp_cap * 3); DALLOC(ctx->mw->pts_b, (size_t)ctx->kp_cap * 3);
+    DALLOC(ctx->mw->st_a, ctx->kp_cap); DALLOC(ctx->mw->st_b, ctx->kp_cap);
+    DALLOC(ctx->mw->xy_a, (size_t)ctx->kp_cap * 2); DALLOC(ctx->mw->xy_b, (size_t)ctx->kp_cap * 2);
+    DALLOC(ctx->mw->mq_idx, ctx->kp_cap); DALLOC(ctx->mw->mt_idx, ctx->kp_cap);
     DALLOC(ctx->red, 4096);
-    ctx->clique_ws_bytes = pose_ws_bytes(ctx->kp_cap);     // sized once: the pose step never reallocates mid-stream
-    DALLOC(ctx->clique_ws, ctx->clique_ws_bytes);
+    ctx->mw->clique_ws_bytes = pose_ws_bytes(ctx->kp_cap);     // sized once: the pose step never reallocates mid-stream
+    DALLOC(ctx->mw->clique_ws, ctx->mw->clique_ws_bytes);
     ctx->pinned_bytes = 8 << 20;
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&ctx->slot_words, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
@@ -232,9 +232,9 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         if (f.ready) (void)hipEventDestroy(f.ready);
     }
     void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->ws->planesL, ctx->ws->planesR,
-                   ctx->ws->C, ctx->ws->S, ctx->ws->sw_bnd, ctx->ws->sw_ctl, ctx->ws->disp_tmp, ctx->dump, ctx->ws->ccl_runlen, ctx->ws->ccl_label, ctx->ws->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
-                   ctx->m_idx, ctx->m_dist, ctx->pts_a, ctx->pts_b, ctx->st_a, ctx->st_b, ctx->xy_a, ctx->xy_b,
-                   ctx->mq_idx, ctx->mt_idx, ctx->red, ctx->clique_ws, ctx->img3_ws, ctx->ransac_ws };
+                   ctx->ws->C, ctx->ws->S, ctx->ws->sw_bnd, ctx->ws->sw_ctl, ctx->ws->disp_tmp, ctx->dump, ctx->ws->ccl_runlen, ctx->ws->ccl_label, ctx->ws->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->mw->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
+                   ctx->mw->m_idx, ctx->mw->m_dist, ctx->mw->pts_a, ctx->mw->pts_b, ctx->mw->st_a, ctx->mw->st_b, ctx->mw->xy_a, ctx->mw->xy_b,
+                   ctx->mw->mq_idx, ctx->mw->mt_idx, ctx->red, ctx->mw->clique_ws, ctx->img3_ws, ctx->mw->ransac_ws };
     for (void* p : ps) if (p) (void)hipFree(p);
     orb_ws_free(*ctx->orbws);
     pose_alt_free(ctx);

@@ -161,23 +161,22 @@ struct vo_ctx {
     int cand_cap = 0;
     uint8_t* host_mask_dev = nullptr;  // explicit mask upload (scratch)
 
-    // match / pose workspace
+    // match / pose workspace.  MatchWs = what one matching + pose (or essential-matrix) step writes; the context owns one
+    // (`main_mw`) and one per asynchronous alternate, `mw` names the one the code in match.hip / geom.hip / ransac.hip works in
+    // right now (PoseScope / MonoScope retarget it together with the stream; nothing is swapped member by member).
+    struct MatchWs {
+        int32_t *m_idx = nullptr, *m_count = nullptr, *m_dist = nullptr, *mq_idx = nullptr, *mt_idx = nullptr;   // m_count: match counter of the ratio filter
+        float *pts_a = nullptr, *pts_b = nullptr, *xy_a = nullptr, *xy_b = nullptr;
+        uint8_t *st_a = nullptr, *st_b = nullptr, *clique_ws = nullptr;
+        size_t clique_ws_bytes = 0;
+        uint8_t* ransac_ws = nullptr;
+        size_t ransac_ws_bytes = 0;
+    };
+    MatchWs main_mw;
+    MatchWs* mw = &main_mw;
     uint8_t* mq = nullptr;
     uint8_t* mt = nullptr;
-    int32_t* m_idx = nullptr;
-    int32_t* m_count = nullptr;    // match counter of the ratio filter
-    int32_t* m_dist = nullptr;
-    float* pts_a = nullptr;
-    float* pts_b = nullptr;
-    uint8_t* st_a = nullptr;
-    uint8_t* st_b = nullptr;
-    float* xy_a = nullptr;
-    float* xy_b = nullptr;
-    int32_t* mq_idx = nullptr;
-    int32_t* mt_idx = nullptr;
     double* red = nullptr;         // reduction scratch
-    uint8_t* clique_ws = nullptr;
-    size_t clique_ws_bytes = 0;
     // asynchronous pose steps (vo_pose_pair_begin / _end): two alternates of the match / pose scratch above,
     // each with its own stream, a pinned result record and a completion event
     static const int N_POSE_ALT = VO_NUM_POSE_ASYNC;
@@ -194,10 +193,7 @@ struct vo_ctx {
         bool ready = false, busy = false;
         int slot_a = -1, slot_b = -1;
         double params[4] = {0, 0, 0, 0};   // ratio, min_matches, rigidity_thr, outlier_thr
-        int32_t *m_idx = nullptr, *m_count = nullptr, *m_dist = nullptr, *mq_idx = nullptr, *mt_idx = nullptr;
-        float *pts_a = nullptr, *pts_b = nullptr, *xy_a = nullptr, *xy_b = nullptr;
-        uint8_t *st_a = nullptr, *st_b = nullptr, *clique_ws = nullptr;
-        size_t clique_ws_bytes = 0;
+        MatchWs mw;
     } pose_alt[N_POSE_ALT];
     int pose_next = 0;
     // asynchronous monocular pair steps (vo_mono_pair_begin / _end): match scratch + RANSAC workspace + stream + pinned record each
@@ -209,14 +205,9 @@ struct vo_ctx {
         size_t result_bytes = 0;
         bool ready = false, busy = false, want = false;
         int nq = 0, nb = 0, min_n = 0;
-        int32_t *m_idx = nullptr, *m_count = nullptr, *m_dist = nullptr, *mq_idx = nullptr, *mt_idx = nullptr;
-        float *xy_a = nullptr, *xy_b = nullptr;
-        uint8_t* ransac_ws = nullptr;
-        size_t ransac_ws_bytes = 0;
+        MatchWs mw;
     } mono_alt[N_MONO_ALT];
     int mono_next = 0;
-    uint8_t* ransac_ws = nullptr;
-    size_t ransac_ws_bytes = 0;
     float* img3_ws = nullptr;
     size_t img3_ws_bytes = 0;
     void* pinned = nullptr;        // pinned host buffer: first 4 KB scalar readbacks, rest = transfer arena
