@@ -45,3 +45,56 @@ def test_rectify_rotated_rig_is_consistent():
     xd = x * kr + 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x)
     yd = y * kr + k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y
     assert np.allclose(np.stack([xd * c.f + c.cx, yd * c.f + c.cy], 1), pts, atol=1e-6)
+
+
+def _recover_pose_loop(E, x1, x2):
+    """the four-candidate cheirality vote written out candidate by candidate (what mono.recover_pose computed before it
+    evaluated each rotation once for both signs of t)"""
+    from openvo_amd.mono import decompose_essential
+    R1, R2, t = decompose_essential(E)
+    best, arg = -1, None
+    h1 = np.c_[x1, np.ones(len(x1))]
+    h2 = np.c_[x2, np.ones(len(x2))]
+    for R in (R1, R2):
+        for tt in (t, -t):
+            a = h1 @ R.T
+            num = np.cross(h2, np.broadcast_to(tt, h2.shape))
+            den = np.cross(a, h2)
+            z1 = np.sum(num * den, 1) / np.maximum(np.sum(den * den, 1), 1e-300)
+            z2 = np.sum((z1[:, None] * a + tt) * h2, 1) / np.sum(h2 * h2, 1)
+            good = int(np.sum((z1 > 0) & (z2 > 0)))
+            if good > best:
+                best, arg = good, (R, tt)
+    return arg[0], arg[1], best
+
+
+def test_mono_recover_pose_known_motions_and_candidate_vote():
+    """E -> (R, t) of the monocular odometer (host arithmetic): exact motions are recovered, and the shared evaluation of the
+    (R, +t) / (R, -t) candidates picks the same candidate with the same vote as the candidate-by-candidate loop -- also with noisy
+    points, points behind the camera and a pure rotation (t arbitrary: only the choice has to agree)."""
+    from openvo_amd.mono import recover_pose
+    rng = np.random.default_rng(11)
+
+    def rot(v):
+        return calib.rodrigues_vec_to_mat(np.asarray(v, np.float64))
+
+    for trial in range(120):
+        R = rot(rng.normal(size=3) * rng.uniform(0.01, 0.8))
+        t = rng.normal(size=3)
+        t /= np.linalg.norm(t)
+        X = rng.uniform(-1, 1, (200, 3)) + [0, 0, rng.uniform(1.5, 6)]
+        if trial % 5 == 4:
+            X[:20, 2] *= -1                                            # a few points behind the first camera
+        x1 = X[:, :2] / X[:, 2:]
+        Y = X @ R.T + t
+        x2 = Y[:, :2] / Y[:, 2:]
+        if trial % 3 == 2:
+            x2 = x2 + rng.normal(size=x2.shape) * 2e-3
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        E = tx @ R
+        Rg, tg, ng = recover_pose(E, x1, x2)
+        Rl, tl, nl = _recover_pose_loop(E, x1, x2)
+        assert ng == nl and np.array_equal(Rg, Rl) and np.array_equal(tg, tl), trial
+        if trial % 3 != 2 and trial % 5 != 4:
+            assert np.allclose(Rg, R, atol=1e-9) and np.allclose(tg, t, atol=1e-9) and ng > len(X) // 2, trial   # (a large rotation
+            # leaves some points behind the second camera: they do not vote)
