@@ -98,3 +98,88 @@ def test_mono_recover_pose_known_motions_and_candidate_vote():
         if trial % 3 != 2 and trial % 5 != 4:
             assert np.allclose(Rg, R, atol=1e-9) and np.allclose(tg, t, atol=1e-9) and ng > len(X) // 2, trial   # (a large rotation
             # leaves some points behind the second camera: they do not vote)
+
+
+class _FakeMonoContext:
+    """Stands in for the native context under MonoOdometer: frames are their indices, a pair step's outcome is a function of the
+    two frames it was begun on.  Records which steps were begun, collected and which slots were handed back."""
+    kp_cap = 64
+
+    def __init__(self, n_frames, few_keypoints=(), rejected=()):
+        self.few, self.rejected = set(few_keypoints), set(rejected)
+        self.frame_of, self.open, self.begun, self.ended = {}, {}, [], []
+        self.next_ticket = 0
+
+    def stage_pairs(self, pairs):
+        self.n = len(pairs)
+
+    def lookahead_drop(self, slot):
+        pass
+
+    def load_staged_pair(self, slot, idx, pre):
+        self.frame_of[slot] = idx
+
+    def prefetch_staged_mono(self, slot, idx, nf):
+        self.frame_of[slot] = idx
+
+    def slot_ready(self, slot):
+        return True
+
+    def orb_slot_count(self, slot, nf, mode):
+        return 3 if self.frame_of[slot] in self.few else 40
+
+    def download_keypoints_xy(self, slot):
+        return np.zeros((40, 2), np.float32)
+
+    def mono_pair_begin(self, a, b, *args, **kw):
+        assert len(self.open) < 5, "more steps open than alternates"
+        t = self.next_ticket
+        self.next_ticket += 1
+        self.open[t] = (self.frame_of[a], self.frame_of[b])
+        self.begun.append(self.open[t])
+        return t
+
+    def mono_pair_end(self, ticket, want_matches=False):
+        fa, fb = self.open.pop(ticket)
+        self.ended.append((fa, fb))
+        bad = fb in self.rejected
+        m = 30
+        return {"E": np.eye(3), "matches": m, "best_iter": fa * 100 + fb, "best_count": 2 if bad else 25,
+                "mask": np.ones(m, np.uint8), "q": np.arange(m, dtype=np.int32), "t": np.arange(m, dtype=np.int32),
+                "xy_b": np.zeros((self.kp_cap, 2), np.float32)}
+
+    def close(self):
+        pass
+
+
+def test_mono_odometer_speculation_bookkeeping(monkeypatch):
+    """MonoOdometer's host logic alone (a scripted context): with pair steps begun ahead, a frame with too few keypoints and
+    a rejected frame void exactly the steps whose premise fell, every begun step is collected, and what update() reports --
+    flags, causes, the pair each decision was taken on -- equals the run without speculation."""
+    from openvo_amd import mono
+    monkeypatch.setattr(mono, "recover_pose", lambda E, x1, x2: (np.eye(3), np.array([0.0, 0.0, 1.0]), len(x1)))
+    out = {}
+    for spec in (0, 3):
+        ctx = _FakeMonoContext(12, few_keypoints={3}, rejected={6, 7})
+        odo = mono.MonoOdometer(np.array([[100.0, 0, 32], [0, 100.0, 24], [0, 0, 1]]), (64, 48), nfeatures=40, min_inliers=10,
+                                context=ctx)
+        odo.speculate, odo.lookahead = spec, 5
+        odo.stage_frames(list(range(12)))
+        log = []
+        for k in range(12):
+            ok = odo.update(k)
+            log.append((ok, "" if ok else odo.skip_cause, None if odo.last is None else odo.last["best_iter"]))
+        odo.close()
+        assert not ctx.open, "steps left open"
+        assert sorted(ctx.begun) == sorted(ctx.ended)
+        out[spec] = (log, dict(odo.speculation), list(ctx.begun), odo.c_T_w.copy())
+    assert out[0][0] == out[3][0]
+    assert np.array_equal(out[0][3], out[3][3])
+    flags = [x[0] for x in out[3][0]]
+    assert flags == [True, True, True, False, True, True, False, False, True, True, True, True]
+    assert out[3][0][3][1] == "keypoints" and out[3][0][6][1] == "inliers" and out[3][0][7][1] == "inliers"
+    # decisions were taken on (reference, frame): 2 stays the reference over the frame with few keypoints, 5 over the rejected ones
+    assert [x[2] for x in out[3][0]][4] == 2 * 100 + 4 and [x[2] for x in out[3][0]][8] == 5 * 100 + 8
+    assert out[0][1] == {"begun": 0, "used": 0, "void": 0}
+    s = out[3][1]
+    assert s["used"] >= 5 and s["void"] >= 2 and len(out[3][2]) > len(out[0][2])
