@@ -511,6 +511,32 @@ def test_host_staging_thread_begin_wait_fetch_and_prefetch():
         ctx.host_stage_wait(-1)
 
 
+@pytest.mark.parametrize("env", [{"VO_STAGGER": "0"}, {"VO_STAGGER": "2", "VO_ENGINES": "5"}, {"VO_POSE_AHEAD": "0"},
+                                 {"VO_POSE_AHEAD": "7", "VO_LOOKAHEAD": "9"}])
+def test_scheduling_knobs_change_nothing_but_the_order(env, monkeypatch):
+    """The staggered start of the look-ahead engines (VO_STAGGER), the number of engines and how many pose steps are begun
+    ahead (VO_POSE_AHEAD) only order work on the device: a staged stream gives bit-identical flags and poses under any of them."""
+    c = Corridor("C1")
+    frames = c.pairs(0, 14)
+    kw = dict(preprocessed_frames=True, rigidity_threshold=0.1, outlier_threshold=0.02)
+
+    def chain():
+        cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=500)
+        odo = StereoOdometer(cam, **kw)
+        staged = cam.stage_pairs(frames)
+        out = [(odo.update(s, None), odo.c_T_w.copy()) for s in staged]
+        cam._ctx.close()
+        return out
+
+    want = chain()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = chain()
+    assert sum(a for a, _ in want) >= 12
+    for (a, Ta), (b, Tb) in zip(got, want):
+        assert a == b and np.array_equal(Ta, Tb)
+
+
 def test_lookahead_depth_counts_what_is_really_in_flight():
     """vo_lookahead_depth: pairs submitted ahead and neither consumed nor dropped.  A reset of the look-ahead (and a fresh
     stage_pairs) must bring it back to zero although the dropped slots' work may still be running."""
