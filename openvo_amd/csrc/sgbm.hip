@@ -1218,9 +1218,9 @@ static int launch_diag_k(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int
     memset(&jobs, 0, sizeof(jobs));
     jobs.n = 1;
     jobs.nstrips = div_up(g.W1 + g.H - 1, UW);
-    // boundary granules of this workspace: [strip][H + 1 rows][NP][64 lanes] x 8 bytes, allocated (and cleared: tags start at
+    // boundary granules of this workspace: [strip][H + 1 rows][NP][48 lanes] x 8 bytes, allocated (and cleared: tags start at
     // 1, no stale granule may match) when first needed or outgrown
-    const size_t need = (size_t)jobs.nstrips * (g.H + 1) * 64 * NP * sizeof(uint64_t);
+    const size_t need = (size_t)jobs.nstrips * (g.H + 1) * DG_GLANES * NP * sizeof(uint64_t);
     if (need > ctx->ws->sw_bnd_bytes) {
         if (ctx->ws->sw_bnd) (void)hipFree(ctx->ws->sw_bnd);
         ctx->ws->sw_bnd = nullptr; ctx->ws->sw_bnd_bytes = 0;
