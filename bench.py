@@ -56,6 +56,11 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs the single-thread CPU baseline is timed on (0 = skip both CPU legs)")
     ap.add_argument("--no-post", action="store_true", help="skip the untimed post-passes (per-stage breakdown, from-host rate, other configs)")
     ap.add_argument("--no-other", action="store_true", help="skip the C4 / C5 runs attached to the C2 line as `other_configs`")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="cold-start windows of --steps pairs each, back to back on consecutive frames; `value` is their median "
+                         "(capped so that at most 600 frames are rendered)")
+    ap.add_argument("--steady", type=int, default=480,
+                    help="pairs of the untimed-for-`value` steady-state pass reported as `steady_state` (0 = skip)")
     args = ap.parse_args()
 
     from openvo_amd import sharding
@@ -106,10 +111,19 @@ def bench_stereo(args, group, device, workload, K, W, light):
     cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), sgbm, (c.w, c.h), device=device,
                        max_keypoints=ODO_KW["nfeatures"])
     odo = StereoOdometer(cam, **ODO_KW)
-    # this rank's frames: W warm-up frames (they also provide the halo) then K timed frames
-    first = rank * K
-    frames = c.pairs(first, W + K)
-    staged = cam.stage_pairs(frames)          # inputs resident in HBM before the clock starts
+    # this rank's frames: W warm-up frames (they also provide the halo), then R windows of K timed frames each on consecutive
+    # frames (`value` = the median window).  The steady-state pass walks the same frames forwards and backwards (consecutive
+    # frames either way: every step is a real pair of the sequence with the same work) so that nothing more has to be rendered.
+    R = 1 if (light or args.from_host) else max(1, min(args.repeats, max(1, (600 - W) // K)))
+    n_unique = W + R * K
+    first = rank * R * K
+    frames = c.pairs(first, n_unique)
+    S_steady = 0 if (light or args.no_post or args.from_host or args.ndisp) else max(0, args.steady)
+    walk = list(range(n_unique))
+    while S_steady and len(walk) < W + S_steady:          # 0 .. n-1, n-2 .. 0, 1 .. n-1, ...
+        walk += list(range(n_unique - 2, -1, -1)) + list(range(1, n_unique))
+    walk = walk[:max(n_unique, W + S_steady)]
+    staged = cam.stage_pairs([frames[i] for i in walk])   # inputs resident in HBM before any clock starts
     ctx = cam._ctx
 
     def sync_all():
@@ -131,28 +145,68 @@ def bench_stereo(args, group, device, workload, K, W, light):
     # kernel only: event packets around every small stage would perturb the throughput measured
     ctx.enable_timing(not args.no_events, stages=["sgbm_wta"])
     ctx.timings(reset=True)
-    rel, acc = [], []
-    cam.reset_lookahead()      # nothing computed before the clock starts may be used inside the timed region
-    sync_all()
-    t0 = time.perf_counter()
-    if args.from_host and not light:
-        before = odo.c_T_w
-        for ok in odo.run(frames[W:W + K]):
-            acc.append(bool(ok))
-            rel.append(sharding.relative_from_chain(before, odo.c_T_w) if ok else np.eye(4))
-            before = odo.c_T_w
-    else:
-        for i in range(W, W + K):
-            before = odo.c_T_w
-            ok = odo.update(staged[i], None)
-            acc.append(bool(ok))
-            rel.append(sharding.relative_from_chain(before, odo.c_T_w) if ok else np.eye(4))
-    ctx.synchronize()                         # every stream of this rank's context has drained: this rank's K steps are done
-    dt = time.perf_counter() - t0             # (the MAX over ranks is taken below; the closing barrier is not part of any rank's work)
-    group.barrier()
-    gc.enable()
+    rel, acc, dts = [], [], []
+
+    def window(od, lo, n, record):
+        """n update() steps on staged[lo : lo + n] from a cold start: every stream drained and every look-ahead result
+        dropped before the clock starts, every stream drained before it stops; returns this rank's seconds."""
+        od.reset_lookahead()       # nothing computed before the clock starts may be used inside the timed region
+        cam.lookahead_stop = lo + n    # ... and nothing beyond the window is started inside it: exactly n pairs of work
+        sync_all()
+        t0 = time.perf_counter()
+        if args.from_host and not light:
+            before = od.c_T_w
+            for ok in od.run(frames[lo:lo + n]):
+                acc.append(bool(ok))
+                rel.append(sharding.relative_from_chain(before, od.c_T_w) if ok else np.eye(4))
+                before = od.c_T_w
+        else:
+            for i in range(lo, lo + n):
+                before = od.c_T_w
+                ok = od.update(staged[i], None)
+                if record:
+                    acc.append(bool(ok))
+                    rel.append(sharding.relative_from_chain(before, od.c_T_w) if ok else np.eye(4))
+        ctx.synchronize()                         # every stream of this rank's context has drained: this rank's n steps are done
+        dt = time.perf_counter() - t0             # (the MAX over ranks is taken below; the closing barrier is not part of any rank's work)
+        group.barrier()
+        cam.lookahead_stop = None
+        return dt
+
+    for r in range(R):                            # R windows of exactly K steps each, on consecutive frames
+        dts.append(window(odo, W + r * K, K, True))
     tm = ctx.timings(reset=True)
+    ctx.enable_timing(False)
+    odo.reset_lookahead()
     sweep_err = ctx.sgbm_sweep_status()
+    # the same K-step window with the reference's own default odometer (rigidity_threshold = outlier_threshold = 0,
+    # /root/reference/src/openVO/stereo_odometer.py:14-15) and a long steady-state pass -- neither is `value`
+    dt_default = dt_steady = None
+    steady_acc = 0
+    if not (light or args.no_post or args.from_host):
+        kw = dict(ODO_KW, rigidity_threshold=0, outlier_threshold=0)
+        dodo = StereoOdometer(cam, **kw)
+        for i in range(W):
+            dodo.update(staged[i], None)
+        dt_default = window(dodo, W, K, False)
+        dodo.reset_lookahead()
+    if S_steady:
+        sodo = StereoOdometer(cam, **ODO_KW)
+        for i in range(W):
+            sodo.update(staged[i], None)
+        sodo.reset_lookahead()
+        cam.lookahead_stop = W + S_steady
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(W, W + S_steady):
+            steady_acc += bool(sodo.update(staged[i], None))
+        ctx.synchronize()
+        dt_steady = time.perf_counter() - t0
+        group.barrier()
+        cam.lookahead_stop = None
+        sodo.reset_lookahead()
+        sweep_err |= ctx.sgbm_sweep_status()
+    gc.enable()
     schedule = {1: "diag", 2: "diag_ragged", 3: "unfused"}.get(ctx.sgbm_last_schedule(), "?")
 
     tb, nb, from_host_rate, copy_gbs = None, 0, None, None
@@ -181,7 +235,7 @@ def bench_stereo(args, group, device, workload, K, W, light):
         # numpy arrays -- 8 untimed pairs, then 96 timed ones whatever K is (a 20-pair window would mostly time the start
         # of the staging thread and the pipeline's fill)
         nh = 96
-        hframes = c.pairs(first + W + K, 8 + nh)
+        hframes = c.pairs(first + n_unique, 8 + nh)
         hodo = StereoOdometer(cam, **ODO_KW)
         cam.reset_lookahead()
         for ok in hodo.run(hframes[:8]):
@@ -193,7 +247,12 @@ def bench_stereo(args, group, device, workload, K, W, light):
         ctx.synchronize()
         from_host_rate = nh / (time.perf_counter() - th)
 
-    dt_max = group.all_reduce_max(dt)         # max over ranks of the timed region
+    dt_windows = [group.all_reduce_max(d) for d in dts]      # per window: max over ranks of the timed region
+    dt_max = float(np.median(dt_windows))                    # `value` comes from the median window
+    if dt_default is not None:
+        dt_default = group.all_reduce_max(dt_default)
+    if dt_steady is not None:
+        dt_steady = group.all_reduce_max(dt_steady)
     # final pose gather (the path's only exchange): 16 float64 + accept flag per frame
     all_rel, all_ok = group.gather_relative(np.array(rel), np.array(acc, np.float64))
 
@@ -205,21 +264,24 @@ def bench_stereo(args, group, device, workload, K, W, light):
         P = 8 if workload == "C4" else 5
         alg_bytes = 2.0 * cells * npaths          # the int16 cost volume read once per direction the kernel covers (3)
         survey_bytes = 2.0 * cells * (1 + P)      # A_sgbm = 2 B * V * (1 + P) for the whole pair
-        traffic, per_pair = None, None
+        traffic, per_pair, traffic_rev = None, None, "unknown"
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
                 traffic, per_pair = tj.get("dominant_kernel_bytes_per_launch"), tj.get("sgbm_bytes_per_pair")
+                traffic_rev = tj.get("source", "unknown")
                 if not isinstance(per_pair, (int, float)):        # (a profile file of an older layout)
                     per_pair = None
             except Exception:
                 traffic = per_pair = None
         roof = {"bound": "hbm",
                 "kernel": "k_sgbm_diag (forward diagonal sweep: NW / N / NE of the %d directions + the W+E volume + winner-take-all; "
-                          "schedule '%s' on every one of the %d timed pairs)" % (P, schedule, K),
+                          "schedule '%s' on every one of the %d timed pairs)" % (P, schedule, R * K),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "bytes_per_launch": alg_bytes,
-                "schedule_counts": {schedule: K}}
+                "traffic_source": ("committed file profiles/traffic_%s.json, NOT measured in this run (PMC counters need rocprofv3 "
+                                   "around the process): %s" % (workload, traffic_rev)) if traffic is not None else None,
+                "schedule_counts": {schedule: R * K}}
         if tb is not None:
             iso_ms, iso_n = tb["sgbm_wta"]
             iso_s = (iso_ms / 1e3) / max(iso_n, 1)
@@ -267,7 +329,27 @@ def bench_stereo(args, group, device, workload, K, W, light):
             "roofline": roof,
             "accepted_frames": int(np.sum(all_ok)), "frames": int(len(all_ok)),
             "sgbm_sweep_error": int(sweep_err),
+            # `value` = the median of R cold-start windows of exactly K steps each (consecutive frames of the sequence, every
+            # stream drained and all look-ahead work dropped before each clock starts); the samples, in order:
+            "window_values": [round(K * world / d, 2) for d in dt_windows],
+            "window_ms": [round(1e3 * d, 3) for d in dt_windows],
+            "cores_per_rank": cores_per_rank(world),
         }
+        if dt_default:
+            out["default_odometer"] = {
+                "value": round(K * world / dt_default, 3), "unit": "frame-pairs/s", "steps": K, "ms_per_step": round(1e3 * dt_default / K, 4),
+                "odometer": {"rigidity_threshold": 0, "outlier_threshold": 0},
+                "note": "one cold-start window of the same K steps with the reference's default odometer "
+                        "(stereo_odometer.py:14-15): no clique filter, no outlier pass"}
+        if dt_steady:
+            sv = S_steady * world / dt_steady
+            out["steady_state"] = {
+                "value": round(sv, 3), "unit": "frame-pairs/s", "steps": S_steady, "ms_per_step": round(1e3 * dt_steady / S_steady, 4),
+                "accepted_frames": int(steady_acc),
+                "aggregate_frac": round(survey_bytes * sv / world / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "one pass of %d update() steps from a cold start (fill and drain included), inputs resident in HBM; the "
+                        "sequence walks this rank's %d rendered frames forwards and backwards (consecutive frames either way)"
+                        % (S_steady, n_unique)}
         if world > 1:
             out["rccl"] = group.describe()        # what the communicator itself reports (ranks, this rank), not a string we made up
         if tb is not None:
@@ -276,12 +358,12 @@ def bench_stereo(args, group, device, workload, K, W, light):
             out["from_host_pairs_per_s"] = round(from_host_rate, 2)    # PCIe-inclusive; never `value`
             out["from_host_window"] = "96 pairs after 8 untimed ones (host numpy arrays through StereoOdometer.run)"
         if world > 1:
-            out["shard_boundaries_inexact"] = sharding.boundary_report(all_ok, K, world)
+            out["shard_boundaries_inexact"] = sharding.boundary_report(all_ok, R * K, world)
         # trajectory error vs the analytic ground truth (information only)
         poses = sharding.compose(all_rel, all_ok)
         if world == 1:
             gt0 = np.linalg.inv(Corridor.gt_pose(first + W - 1))
-            err = [np.linalg.norm(poses[i][:3, 3] - (gt0 @ Corridor.gt_pose(first + W + i))[:3, 3]) for i in range(K)]
+            err = [np.linalg.norm(poses[i][:3, 3] - (gt0 @ Corridor.gt_pose(first + W + i))[:3, 3]) for i in range(R * K)]
             out["ate_vs_ground_truth_m"] = round(float(np.sqrt(np.mean(np.square(err)))), 5)
         if world == 1 and args.cpu_pairs > 0 and not light:
             out["cpu_baseline"], out["ate_vs_cpu_m"] = cpu_baseline(c, cam, sgbm, frames, W, min(args.cpu_pairs, K), odo_poses=poses)
@@ -369,6 +451,14 @@ def bench_c5(args, group, device, K_steps, W):
                "matches_per_pair": int(resid / iters / max(K_steps, 1))}
     odo.close()
     return out if group.rank == 0 else None
+
+
+def cores_per_rank(world):
+    """Host cores this rank may run on (its affinity mask) divided among the ranks of this node: each rank's loop needs
+    about 0.1 ms of one core per step."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", world) or world)
+    return round(n / max(local, 1), 2)
 
 
 # ---- CPU baseline (reported, not the target) ------------------------------------------------------------------

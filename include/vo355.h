@@ -31,7 +31,10 @@ enum {
     VO_E_HIP = -2,     /* HIP runtime error (message has the hipError string) */
     VO_E_STATE = -3,   /* call order violated (e.g. no disparity in that slot yet) */
     VO_E_CAP = -4,     /* capacity given at vo_create exceeded */
-    VO_E_NUMERIC = -5  /* degenerate input (Umeyama: <3 points / colinear) */
+    VO_E_NUMERIC = -5, /* degenerate input (Umeyama: <3 points / colinear) */
+    VO_E_SWEEP = -6    /* the disparity a result depends on is undefined: a strip hand-off inside the aggregation sweep of that
+                          pair gave up waiting (an oversubscribed GPU).  Nothing computed from it is handed out; the pair can be
+                          submitted again.  cv2's StereoSGBM is one sequential pass and cannot fail this way (stereo_camera.py:51) */
 };
 
 #define VO_NUM_SLOTS 28 /* frame slots per context: the odometer keeps prev and current, up to 25 more hold
@@ -277,11 +280,14 @@ int vo_sgbm_last_schedule(vo_ctx* ctx, int* schedule_out);
  * whole one) between two of the context's volumes, timed with HIP events; *gb_per_s counts bytes read + bytes written.
  * Overwrites the cost volume: call it between, not inside, vo_sgbm_compute / vo_prefetch_pair sequences. */
 int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemporal, double* gb_per_s);
-/* health of the diagonal aggregation sweeps (synchronises): *error_out != 0 when a wait between strips
- * ever exceeded its poll limit (the affected disparities are then undefined); sticky until vo_destroy */
+/* health of the diagonal aggregation sweeps (synchronises): *error_out = number of SGBM runs of this context in which a wait
+ * between strips exceeded its poll limit (the affected pair's results are refused with VO_E_SWEEP where they are picked up:
+ * vo_sgbm_compute with an output pointer, vo_download_disparity_f32 / _xyz, vo_orb_detect_and_compute with the fused mask,
+ * vo_points3d_at, vo_point_clouds, vo_pose_pair, vo_pose_pair_end); the count is sticky until vo_destroy, a later pair in
+ * the same workspace is unaffected */
 int vo_sgbm_sweep_status(vo_ctx* ctx, int* error_out);
 /* development aid: control block `block` (0 | 1) of the latest aggregation sweep in the main workspace -- word 0 = work items
-   taken, word 1 = sticky error, words 8 + 8 s .. = {start, end, failed polls, ticks waiting, misses} of strip s (100 MHz ticks).
+   taken, word 1 = a wait gave up in this launch (cleared by the next run), words 8 + 8 s .. = {start, end, failed polls, ticks waiting, misses} of strip s (100 MHz ticks).
    No reference counterpart (stereosgbm.cpp is one sequential pass). */
 int vo_sgbm_sweep_stats(vo_ctx* ctx, int block, int32_t* out, int n_words);
 

@@ -46,6 +46,30 @@ class VoError(RuntimeError):
         self.code = code
 
 
+class SweepTimeout(VoError):
+    """VO_E_SWEEP: the disparity a result depends on is undefined (a strip hand-off of that pair's aggregation sweep gave up
+    waiting, e.g. on an oversubscribed GPU).  Nothing computed from it is handed out; the pair can be submitted again."""
+
+
+VO_E_SWEEP = -6
+
+
+def _image_pair(left, right):
+    """(left, right, channels) as C-contiguous uint8 arrays of one shape: HxW or HxWx3 (HxWx1 is squeezed); anything else
+    -- e.g. HxWx4 -- is refused here, before a pointer reaches native code that would read w*h*channels bytes from it."""
+    left, right = np.asarray(left), np.asarray(right)
+    out = []
+    for a in (left, right):
+        if a.ndim == 3 and a.shape[2] == 1:
+            a = a[:, :, 0]
+        if a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+            raise ValueError("an image must be HxW or HxWx3 (got shape %s)" % (a.shape,))
+        out.append(_c(a, np.uint8))
+    if out[0].shape != out[1].shape:
+        raise ValueError("left/right shapes differ")
+    return out[0], out[1], (3 if out[0].ndim == 3 else 1)
+
+
 def build_native(force=False):
     """Compile openvo_amd/csrc/*.hip for gfx950 into openvo_amd/libvo355.so."""
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h", ".inc"))]
@@ -184,7 +208,7 @@ class Context:
 
     def _ck(self, rc):
         if rc != 0:
-            raise VoError(rc, (self._lib.vo_last_error(self._h) or b"").decode())
+            raise (SweepTimeout if rc == VO_E_SWEEP else VoError)(rc, (self._lib.vo_last_error(self._h) or b"").decode())
 
     # ---- configuration
     def device_name(self):
@@ -214,20 +238,14 @@ class Context:
 
     # ---- per pair
     def upload_pair(self, slot, left, right, preprocessed):
-        if left.shape != right.shape:
-            raise ValueError("left/right shapes differ")
-        ch = 3 if left.ndim == 3 else 1
-        left, right = _c(left, np.uint8), _c(right, np.uint8)
+        left, right, ch = _image_pair(left, right)
         h, w = left.shape[:2]
         self._ck(self._lib.vo_upload_pair(self._h, slot, _p(left), _p(right), w, h, ch, int(bool(preprocessed))))
         return w, h
 
     def prefetch_pair(self, slot, left, right, preprocessed):
         """Look-ahead from host images: pinned staging + async upload + SGBM (+ ORB) on an engine."""
-        if left.shape != right.shape:
-            raise ValueError("left/right shapes differ")
-        ch = 3 if left.ndim == 3 else 1
-        left, right = _c(left, np.uint8), _c(right, np.uint8)
+        left, right, ch = _image_pair(left, right)
         h, w = left.shape[:2]
         self._ck(self._lib.vo_prefetch_pair(self._h, slot, _p(left), _p(right), w, h, ch, int(bool(preprocessed))))
         return w, h
@@ -235,8 +253,7 @@ class Context:
     def host_stage_pair(self, buf, left, right):
         """Copy a host pair into pinned staging buffer `buf` (waits for that buffer's previous upload).  The one call that
         may run on a helper thread while another thread drives this context."""
-        ch = 3 if left.ndim == 3 else 1
-        left, right = _c(left, np.uint8), _c(right, np.uint8)
+        left, right, ch = _image_pair(left, right)
         h, w = left.shape[:2]
         rc = self._lib.vo_host_stage_pair(self._h, int(buf), _p(left), _p(right), w, h, ch)
         if rc != 0:
@@ -246,8 +263,7 @@ class Context:
     def host_stage_begin(self, buf, left, right):
         """The same copy on the library's own staging thread: returns at once with (w, h, ch, keep) -- `keep` holds the two
         arrays, which must stay alive and untouched until prefetch_host_staged / host_stage_fetch / host_stage_wait on `buf`."""
-        ch = 3 if left.ndim == 3 else 1
-        left, right = _c(left, np.uint8), _c(right, np.uint8)
+        left, right, ch = _image_pair(left, right)
         h, w = left.shape[:2]
         self._ck(self._lib.vo_host_stage_begin(self._h, int(buf), _p(left), _p(right), w, h, ch))
         return w, h, ch, (left, right)
@@ -267,13 +283,12 @@ class Context:
 
     def stage_pairs(self, pairs):
         """Upload a list of (left, right) host pairs once; they stay resident in HBM."""
-        l0 = np.asarray(pairs[0][0])
-        ch = 3 if l0.ndim == 3 else 1
+        l0, _, ch = _image_pair(*pairs[0])
         h, w = l0.shape[:2]
         self._ck(self._lib.vo_stage_pairs_alloc(self._h, len(pairs), w, h, ch))
         for i, (l, r) in enumerate(pairs):
-            l, r = _c(l, np.uint8), _c(r, np.uint8)
-            if l.shape != l0.shape or r.shape != l0.shape:
+            l, r, _ = _image_pair(l, r)
+            if l.shape != l0.shape:
                 raise ValueError("all staged pairs must share one shape")
             self._ck(self._lib.vo_stage_pair(self._h, i, _p(l), _p(r)))
         self.staged_shape = (w, h)
@@ -621,7 +636,8 @@ class Context:
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(T_STAGES)}
 
     def sgbm_sweep_status(self):
-        """0 = every diagonal sweep so far completed its hand-offs; non-zero = a wait timed out (sticky)."""
+        """Number of SGBM runs of this context whose diagonal sweep gave up a strip hand-off (0 = healthy; sticky).  Results that
+        depend on such a run are refused with SweepTimeout where they are picked up."""
         e = ctypes.c_int(0)
         self._ck(self._lib.vo_sgbm_sweep_status(self._h, ctypes.byref(e)))
         return e.value

@@ -164,7 +164,8 @@ extern "C" int vo_points3d_at(vo_ctx* ctx, int slot, const float* xy, int n, flo
     rc = xfer_d2h(ctx, xyz_out, ctx->mw->pts_a, (size_t)n * 12);
     if (!rc) rc = xfer_d2h(ctx, status_out, ctx->mw->st_a, (size_t)n);
     if (rc) return rc;
-    return xfer_flush(ctx);
+    if ((rc = xfer_flush(ctx))) return rc;
+    return slot_health(ctx, f, slot);
 }
 
 static int ensure_ws(vo_ctx* ctx, float** p, size_t* have, size_t bytes)
@@ -233,7 +234,7 @@ extern "C" int vo_download_xyz(vo_ctx* ctx, int slot, float* out)
     VO_CHECK_LAUNCH(ctx);
     VO_HIP(ctx, hipMemcpyAsync(out, ctx->img3_ws, n * 12, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return VO_OK;
+    return slot_health(ctx, f, slot);
 }
 
 // ---- ratio test + fused point_clouds ----------------------------------------------------
@@ -312,6 +313,7 @@ extern "C" int vo_point_clouds(vo_ctx* ctx, int slot_a, int slot_b, double ratio
         VO_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->mw->m_count, 4, hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if ((rc = slot_health(ctx, a, slot_a)) || (rc = slot_health(ctx, b, slot_b))) return rc;   // (both slots' producers are behind that synchronisation)
     const int m = *(int32_t*)ctx->pinned;
     *m_out = m;
     if (m == 0) return VO_OK;
@@ -1340,6 +1342,7 @@ extern "C" int vo_pose_pair(vo_ctx* ctx, int slot_a, int slot_b, double ratio, i
     if (a.n_kp == 0) return VO_OK;
     if ((rc = pose_enqueue(ctx, a, b, ratio, min_matches, rigidity_thr, outlier_thr, ctx->pinned))) return rc;
     if ((rc = xfer_flush(ctx))) return rc;
+    if ((rc = slot_health(ctx, a, slot_a)) || (rc = slot_health(ctx, b, slot_b))) return rc;   // never a pose from an undefined disparity
     pose_unpack(ctx->pinned, counts4, rc2, T1_12, T2_12);
     return VO_OK;
 }
@@ -1439,6 +1442,7 @@ extern "C" int vo_pose_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
         f->readers[f->readers[0] ? 1 : 0] = p.done;
     }
     p.busy = true; p.slot_a = slot_a; p.slot_b = slot_b;
+    p.gen_a = a.disp_gen; p.gen_b = b.disp_gen;
     p.params[0] = ratio; p.params[1] = min_matches; p.params[2] = rigidity_thr; p.params[3] = outlier_thr;
     ctx->pose_next = (k + 1) % vo_ctx::N_POSE_ALT;
     *ticket_out = k;
@@ -1453,6 +1457,16 @@ extern "C" int vo_pose_pair_end(vo_ctx* ctx, int ticket, int32_t* counts4, int32
     VO_HIP(ctx, hipSetDevice(ctx->device));
     p.busy = false;
     VO_HIP(ctx, hipEventSynchronize(p.done));
+    // the step read the disparities the two slots held when it was begun: were those runs healthy?  (a slot refilled since
+    // then carries another generation and another word value)
+    const int32_t gens[2] = { p.gen_a, p.gen_b };
+    const int slots[2] = { p.slot_a, p.slot_b };
+    for (int i = 0; i < 2; i++) {
+        const FrameSlot& f = ctx->slots[slots[i]];
+        if (gens[i] != 0 && *(volatile int32_t*)f.sweep_word == gens[i])
+            return vo_fail(ctx, VO_E_SWEEP, "pose step %d: the aggregation sweep of the pair in slot %d gave up a strip hand-off: its "
+                                            "disparity is undefined and no pose is derived from it", ticket, slots[i]);
+    }
     pose_unpack(p.result, counts4, rc2, T1_12, T2_12);
     return VO_OK;
 }

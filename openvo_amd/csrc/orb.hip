@@ -777,6 +777,8 @@ extern "C" int vo_orb_detect_and_compute(vo_ctx* ctx, int slot, int nfeatures, i
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(f.kp_params, params, sizeof(params));
     }
+    // (the stream or the slot's `ready` event has been waited for: the SGBM run that produced the fused mask is over)
+    if (mask_mode == 1 && (rc = slot_health(ctx, f, slot))) { f.has_kp = false; return rc; }
     if ((rc = orb_finish(ctx, &f))) return rc;
     return download_kps(ctx, f, kp_xy, kp_size, kp_angle, kp_response, kp_octave, desc, cap, n_out);
 }

@@ -108,11 +108,10 @@ __global__ void k_sgbm_planes(const uint8_t* __restrict__ L, const uint8_t* __re
                               int* __restrict__ sw_ctl, int sw_ctl_words)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    // the diagonal sweeps' work-item tickets and timelines of this run start at zero (word 1 of each of the
-    // two control blocks is its sticky error flag and is left alone)
+    // the diagonal sweeps' work-item tickets, "a wait gave up" words and timelines of this run start at zero (k_sgbm_fin of
+    // the previous run in this workspace has already reported its word to the slot it filled)
     if (y == 0 && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < sw_ctl_words; i += blockDim.x)
-            if ((i % (sw_ctl_words / 2)) != 1) sw_ctl[i] = 0;
+        for (int i = threadIdx.x; i < sw_ctl_words; i += blockDim.x) sw_ctl[i] = 0;
     if (x >= W) return;
     size_t i = (size_t)y * W + x, plane = (size_t)W * H;
     d2key[i] = D2_EMPTY;   // the disp2 candidates of this run start empty (saves a fill launch before the WTA)
@@ -934,10 +933,17 @@ __device__ __forceinline__ void wta_pixel(const LV<NP>& S, const SgbmGeom& g, in
 // Second half of the fused sweep's WTA, one thread per pixel: the sweep leaves a two-word record
 // (aux0 = minS << 8 | best or -1 when the uniqueness test failed, aux1 = S[best-1] << 16 | S[best+1]);
 // this pass turns it into the sub-pixel disp1 and the disp2 candidates (atomicMin).
+// It also reports the run's health: when a wait inside one of its sweeps gave up (word 1 of a control block), the run's
+// generation goes into the pinned word of the slot it fills (FrameSlot::sweep_word) and the context's counter is bumped.
 __global__ void k_sgbm_fin(const int* __restrict__ aux0, const int* __restrict__ aux1, SgbmGeom g,
-                           int16_t* __restrict__ disp1, int* __restrict__ d2key)
+                           int16_t* __restrict__ disp1, int* __restrict__ d2key, const int* __restrict__ ctlA,
+                           const int* __restrict__ ctlB, int* sweep_word, int gen, int* __restrict__ sweep_errs)
 {
     const int x1 = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x1 == 0 && y == 0 && (ctlA[1] | ctlB[1])) {
+        __hip_atomic_store(sweep_word, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        atomicAdd(sweep_errs, 1);
+    }
     if (x1 >= g.W1) return;
     const int ximg = x1 + g.minX1;
     const size_t o = (size_t)y * g.W + ximg;
@@ -1234,6 +1240,11 @@ static int launch_diag_k(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int
     if (j.tag == 0) j.tag = ++ctx->ws->sw_tag;
     j.sink = ctx->max_w * ctx->max_h;          // every pixel array is allocated with 256 spare bytes
     j.dbg = ctx->tune_diag_dbg;
+    j.spin_limit = ctx->tune_spin_limit;
+    if (ctx->fault_sweep > 0 && --ctx->fault_sweep == 0) {   // (only the test-hooks build ever sets it: this launch's strips export
+        j.dbg |= 2;                                          //  nothing, so every import misses and gives up after a few polls)
+        j.spin_limit = 64;
+    }
     const size_t lds = (size_t)DG_RING * 2 * CW * g.Dp * 2 + (WTA ? (size_t)NWC * 4 * 2 * g.Dp * 2 : 0) + 64 * 4;
     auto kern = k_sgbm_diag<NP, PAD, NWC, REV, WTA>;
     static unsigned long long attr_set = 0;     // per instantiation and device: allow more than 64 KB of dynamic LDS
@@ -1273,7 +1284,7 @@ static int launch_diag(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int16
 //     k_sgbm_paths, per-pixel winner search over all of them (k_sgbm_wta)
 // Layout of S (fused): [0] = L_W + L_E, [1] = MODE_HH: [0] + the three bottom-up directions, [2] = checkpoints of step 1.
 template <int NP>
-static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size_t vol)
+static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size_t vol, int* sweep_word, int gen)
 {
     const bool pad = g.D != g.Dp;
     const bool hh = plan.n_dirs == 8;
@@ -1313,7 +1324,8 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
         {
             StageTimer t(ctx, VO_T_SGBM_WTA);
             if (!(ctx->tune_diag_dbg & 16) && (rc = launch_diag<NP, false, true>(ctx, g, hh ? Srev : Swe, nullptr, hh ? ctlB : ctlA))) return rc;
-            hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ws->ccl_label, ctx->ws->ccl_runlen, g, ctx->ws->disp_tmp, ctx->ws->ccl_size);
+            hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ws->ccl_label, ctx->ws->ccl_runlen, g, ctx->ws->disp_tmp, ctx->ws->ccl_size,
+                               ctlA, ctlB, sweep_word, gen, ctx->d_sweep_errs);
             VO_CHECK_LAUNCH(ctx);
         }
         ctx->last_paths = 3;
@@ -1342,15 +1354,17 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
     return VO_OK;
 }
 
-static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);
+static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h);
 
 // The SGBM workspaces (planes, C, S volumes, CCL arrays) are shared by the main and the look-ahead
 // stream: a run on one stream must not start before the previous run -- possibly on the other
 // stream -- has finished.  An event chain orders them on the device without blocking the host.
-int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp)
+int sgbm_run(vo_ctx* ctx, FrameSlot& f, int w, int h)
 {
     if (ctx->ws->done_valid) VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ws->done, 0));
-    int rc = sgbm_run_impl(ctx, dL, dR, w, h, d_disp);
+    if (++ctx->sweep_gen_next <= 0) ctx->sweep_gen_next = 1;     // this run's generation: never 0 (FrameSlot::sweep_word)
+    f.disp_gen = ctx->sweep_gen_next;
+    int rc = sgbm_run_impl(ctx, f, w, h);
     if (ctx->ws->done) {
         VO_HIP(ctx, hipEventRecord(ctx->ws->done, ctx->stream));
         ctx->ws->done_valid = true;
@@ -1358,8 +1372,11 @@ int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, in
     return rc;
 }
 
-static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp)
+static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h)
 {
+    const uint8_t* const dL = f.left;
+    const uint8_t* const dR = f.right;
+    int16_t* const d_disp = f.disp16;
     const SgbmEff& e = ctx->sg;
     if (!e.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");
     SgbmGeom g;
@@ -1415,14 +1432,14 @@ static int sgbm_run_impl(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int 
     }
     int rc;
     switch (g.Dp / 32) {
-        case 1: rc = launch_agg<1>(ctx, g, plan, vol); break;
-        case 2: rc = launch_agg<2>(ctx, g, plan, vol); break;
-        case 3: rc = launch_agg<3>(ctx, g, plan, vol); break;
-        case 4: rc = launch_agg<4>(ctx, g, plan, vol); break;
-        case 5: rc = launch_agg<5>(ctx, g, plan, vol); break;
-        case 6: rc = launch_agg<6>(ctx, g, plan, vol); break;
-        case 7: rc = launch_agg<7>(ctx, g, plan, vol); break;
-        default: rc = launch_agg<8>(ctx, g, plan, vol); break;
+        case 1: rc = launch_agg<1>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
+        case 2: rc = launch_agg<2>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
+        case 3: rc = launch_agg<3>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
+        case 4: rc = launch_agg<4>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
+        case 5: rc = launch_agg<5>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
+        case 6: rc = launch_agg<6>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
+        case 7: rc = launch_agg<7>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
+        default: rc = launch_agg<8>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
     }
     if (rc) return rc;
     if (!(ctx->tune_diag_dbg & 32)) {

@@ -186,10 +186,13 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->mw->clique_ws, ctx->mw->clique_ws_bytes);
     ctx->pinned_bytes = 8 << 20;
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&ctx->slot_words, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&ctx->slot_words, 128 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
         g_create_err = "hipHostMalloc failed"; vo_destroy(ctx); return VO_E_HIP;
     }
-    for (int s = 0; s <= VO_NUM_SLOTS; s++) ctx->slots[s].n_kp_host = ctx->slot_words + s;
+    memset(ctx->slot_words, 0, 128 * sizeof(int32_t));
+    for (int s = 0; s <= VO_NUM_SLOTS; s++) { ctx->slots[s].n_kp_host = ctx->slot_words + s; ctx->slots[s].sweep_word = ctx->slot_words + 64 + s; }
+    DALLOC(ctx->d_sweep_errs, 64);
+    VO_HIP(ctx, hipMemset(ctx->d_sweep_errs, 0, 64 * sizeof(int)));
     if (const char* e8 = getenv("VO_ENGINES")) { int v = atoi(e8); if (v >= 1 && v <= vo_ctx::MAX_ENGINES) ctx->n_engines = v; }
     {
         // every engine owns a full SGBM workspace: cost volume + 3 aggregated volumes + boundary granules (< 1 volume) + planes.
@@ -208,6 +211,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     if (const char* e25 = getenv("VO_DIAG_WAVES")) ctx->tune_diag_nwc = atoi(e25) == 15 ? 15 : 7;
 #ifdef VO_TEST_HOOKS
     if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);   // test-only build (libvo355_hooks.so)
+    if (const char* e11 = getenv("VO_FAULT_SWEEP")) ctx->fault_sweep = atoi(e11);
 #endif
     if (const char* e6 = getenv("VO_SWEEP_TY")) { int v = atoi(e6); if (v >= 4 && v <= 4096) ctx->tune_sweep_ty = v; }
     *out = ctx;
@@ -234,7 +238,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->ws->planesL, ctx->ws->planesR,
                    ctx->ws->C, ctx->ws->S, ctx->ws->sw_bnd, ctx->ws->sw_ctl, ctx->ws->disp_tmp, ctx->dump, ctx->ws->ccl_runlen, ctx->ws->ccl_label, ctx->ws->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->mw->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
                    ctx->mw->m_idx, ctx->mw->m_dist, ctx->mw->pts_a, ctx->mw->pts_b, ctx->mw->st_a, ctx->mw->st_b, ctx->mw->xy_a, ctx->mw->xy_b,
-                   ctx->mw->mq_idx, ctx->mw->mt_idx, ctx->red, ctx->mw->clique_ws, ctx->img3_ws, ctx->mw->ransac_ws };
+                   ctx->mw->mq_idx, ctx->mw->mt_idx, ctx->red, ctx->mw->clique_ws, ctx->img3_ws, ctx->mw->ransac_ws, ctx->d_sweep_errs };
     for (void* p : ps) if (p) (void)hipFree(p);
     orb_ws_free(*ctx->orbws);
     pose_alt_free(ctx);
@@ -653,7 +657,7 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
         if (!rc && ctx->fault_prefetch > 0 && --ctx->fault_prefetch == 0)
             rc = vo_fail(ctx, VO_E_STATE, "injected failure (VO_FAULT_PREFETCH) inside the engine scope");
 #endif
-        if (!rc) rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
+        if (!rc) rc = sgbm_run(ctx, f, w, h);
         if (!rc && ctx->la_orb) {
             const int* q = ctx->la_orb_params;
             rc = orb_slot_enqueue(ctx, f, q[0], q[1], q[2], q[3]);
@@ -896,12 +900,13 @@ extern "C" int vo_sgbm_compute(vo_ctx* ctx, int slot, int16_t* disp16_out)
     if (!f.has_pair) return vo_fail(ctx, VO_E_STATE, "slot %d holds no image pair", slot);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = slot_wait(ctx, f))) return rc;
-    rc = sgbm_run(ctx, f.left, f.right, f.w, f.h, f.disp16);
+    rc = sgbm_run(ctx, f, f.w, f.h);
     if (rc) return rc;
     f.has_disp = true; f.kp_pending = false; f.has_kp = false;
     if (disp16_out) {
         VO_HIP(ctx, hipMemcpyAsync(disp16_out, f.disp16, (size_t)f.w * f.h * 2, hipMemcpyDeviceToHost, ctx->stream));
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return slot_health(ctx, f, slot);
     }
     return VO_OK;
 }
@@ -914,11 +919,11 @@ extern "C" int vo_sgbm_compute_host(vo_ctx* ctx, const uint8_t* left, const uint
     FrameSlot& f = ctx->slots[VO_NUM_SLOTS];
     VO_HIP(ctx, hipMemcpyAsync(f.left, left, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
     VO_HIP(ctx, hipMemcpyAsync(f.right, right, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
-    int rc = sgbm_run(ctx, f.left, f.right, w, h, f.disp16);
+    int rc = sgbm_run(ctx, f, w, h);
     if (rc) return rc;
     VO_HIP(ctx, hipMemcpyAsync(disp16_out, f.disp16, (size_t)w * h * 2, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return VO_OK;
+    return slot_health(ctx, f, VO_NUM_SLOTS);
 }
 
 extern "C" int vo_cvt_bgr2gray(vo_ctx* ctx, const uint8_t* bgr, int w, int h, uint8_t* gray)
@@ -983,7 +988,7 @@ extern "C" int vo_download_disparity_f32(vo_ctx* ctx, int slot, float* out)
     VO_CHECK_LAUNCH(ctx);
     VO_HIP(ctx, hipMemcpyAsync(out, ctx->img3_ws, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return VO_OK;
+    return slot_health(ctx, f, slot);
 }
 
 extern "C" int vo_download_left(vo_ctx* ctx, int slot, uint8_t* out)
@@ -1076,26 +1081,25 @@ extern "C" int vo_get_timings(vo_ctx* ctx, double* ms_out, int64_t* launches_out
     return VO_OK;
 }
 
+// the disparity a slot holds comes from a run whose diagonal sweep gave up a strip hand-off (see FrameSlot::sweep_word)
+int slot_health(vo_ctx* ctx, const FrameSlot& f, int slot)
+{
+    if (f.disp_gen != 0 && f.sweep_word && *(volatile int32_t*)f.sweep_word == f.disp_gen)
+        return vo_fail(ctx, VO_E_SWEEP, "slot %d: a strip hand-off of this pair's aggregation sweep gave up waiting (GPU oversubscribed?): "
+                                        "its disparity is undefined and nothing computed from it is handed out; submit the pair again", slot);
+    return VO_OK;
+}
+
 extern "C" int vo_sgbm_sweep_status(vo_ctx* ctx, int* error_out)
 {
     if (!ctx || !error_out) return VO_E_ARG;
     VO_HIP(ctx, hipSetDevice(ctx->device));
     int rc = vo_synchronize(ctx);
     if (rc) return rc;
-    // word 1 of each control block of every workspace: set (and never cleared) when a wait inside a diagonal
-    // sweep exceeded its poll limit
-    int any = 0;
-    int* blocks[vo_ctx::MAX_ENGINES + 1] = { ctx->ws->sw_ctl };
-    for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) blocks[k + 1] = ctx->ws_alt[k].sw_ctl;
-    for (int* b : blocks) {
-        if (!b) continue;
-        for (int half = 0; half < 2; half++) {
-            int v = 0;
-            VO_HIP(ctx, hipMemcpy(&v, b + half * (ctx->sw_ctl_words / 2) + 1, sizeof(int), hipMemcpyDeviceToHost));
-            any |= v;
-        }
-    }
-    *error_out = any;
+    // SGBM runs of this context in which a wait inside a diagonal sweep exceeded its poll limit (counted by k_sgbm_fin)
+    int n = 0;
+    VO_HIP(ctx, hipMemcpy(&n, ctx->d_sweep_errs, sizeof(int), hipMemcpyDeviceToHost));
+    *error_out = n;
     return VO_OK;
 }
 

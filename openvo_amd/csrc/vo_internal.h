@@ -54,6 +54,12 @@ struct FrameSlot {
     // in the slot's pinned word once `ready` has fired
     int32_t* n_kp_host = nullptr;
     bool kp_pending = false;
+    // health of the disparity in this slot: every SGBM run gets a generation number (disp_gen, never 0); a run whose diagonal
+    // sweep gave up a strip hand-off (its disparity is then undefined) writes ITS generation into the slot's pinned word from
+    // the device (k_sgbm_fin).  The slot is bad exactly while *sweep_word == disp_gen: a refill gets a new generation, a late
+    // write of an older run can never match it.  Checked wherever the host picks up results that depend on the disparity.
+    int32_t* sweep_word = nullptr;
+    int32_t disp_gen = 0;
     int kp_params[4] = {0, 0, 0, 0};   // nfeatures, mask_mode, min_disp16, max_disp16 of the pending run
 };
 
@@ -109,7 +115,11 @@ struct vo_ctx {
     // ORB behind the look-ahead SGBM (vo_set_lookahead_orb): nfeatures, mask_mode, min/max disp16
     bool la_orb = false;
     int la_orb_params[4] = {0, 0, 0, 0};
-    int32_t* slot_words = nullptr;   // pinned, one word per slot (keypoint counts of pending runs)
+    int32_t* slot_words = nullptr;   // pinned: one word per slot (keypoint counts of pending runs), then one per slot for FrameSlot::sweep_word
+    int32_t sweep_gen_next = 0;      // generations handed to SGBM runs so far
+    int* d_sweep_errs = nullptr;     // device counter: SGBM runs of this context whose sweep gave up a hand-off (vo_sgbm_sweep_status)
+    int tune_spin_limit = 1 << 22;   // polls before a wait inside the diagonal sweep is declared dead
+    int fault_sweep = 0;             // VO_FAULT_SWEEP=n (VO_TEST_HOOKS builds only): the n-th diagonal sweep exports nothing and gives up after a few polls
     int n_engines = 16;              // VO_ENGINES (needs GPU_MAX_HW_QUEUES >= engines + 4: streams sharing a hardware queue serialise)
     int next_engine = 0;
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;
@@ -192,6 +202,7 @@ struct vo_ctx {
         void* result = nullptr;        // pinned PoseOut
         bool ready = false, busy = false;
         int slot_a = -1, slot_b = -1;
+        int32_t gen_a = 0, gen_b = 0;      // disparity generations of the two slots when the step was begun (slot health at _end)
         double params[4] = {0, 0, 0, 0};   // ratio, min_matches, rigidity_thr, outlier_thr
         MatchWs mw;
     } pose_alt[N_POSE_ALT];
@@ -297,7 +308,10 @@ __global__ void k_ratio_compact(const int32_t* idx, const int32_t* dist, int nq,
                                 int32_t* q_out, int32_t* t_out, float* xyq_out, float* xyt_out, int32_t* m_out);   // pose / clique scratch for nq query keypoints
 
 // implemented in the per-stage files
-int sgbm_run(vo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int w, int h, int16_t* d_disp);
+int sgbm_run(vo_ctx* ctx, FrameSlot& f, int w, int h);     // f.left, f.right (w x h) -> f.disp16; gives the run its generation
+// VO_E_SWEEP when the disparity the slot holds comes from a run whose sweep gave up a hand-off.  Only meaningful once the host
+// has waited for work that depends on that run (a stream or event synchronisation).
+int slot_health(vo_ctx* ctx, const FrameSlot& f, int slot);
 int orb_prepare_tables(vo_ctx* ctx, int w, int h);
 int orb_run(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img_stride, int w, int h,
             int nfeatures, int mask_mode, const int16_t* d_disp16, int disp_stride, int min_d16,

@@ -144,6 +144,7 @@ class StereoCamera:
         self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "18"))
         self._lookahead = []         # [((index, preprocessed), slot, (w, h))] of the pairs in flight
         self._n_staged = 0
+        self.lookahead_stop = None   # staged pairs at or beyond this index are never started ahead (None: up to the last staged pair)
 
     # ---- slot bookkeeping -------------------------------------------------------------------
     def _release_slot(self, slot, frame):
@@ -332,7 +333,8 @@ class StereoCamera:
             # start the NEXT staged pairs on the look-ahead streams: their disparity overlaps this
             # pair's ORB / matching / pose kernels (only into free slots -- never evict for a guess)
             have = {h[0][0] for h in self._lookahead}
-            for idx in range(img_left.index + 1, min(img_left.index + 1 + int(self.lookahead), self._n_staged)):
+            stop = self._n_staged if self.lookahead_stop is None else min(self._n_staged, int(self.lookahead_stop))
+            for idx in range(img_left.index + 1, min(img_left.index + 1 + int(self.lookahead), stop)):
                 if idx in have:
                     continue
                 nxt = self._free_slot()

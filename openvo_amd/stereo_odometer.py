@@ -96,7 +96,12 @@ class StereoOdometer:
 
     # ------------------------------------------------------------------------------------------
     def update(self, img_left, img_right):
-        """Process one stereo pair; True when the frame was accepted  [reference :115-160]."""
+        """Process one stereo pair; True when the frame was accepted  [reference :115-160].
+
+        Raises _native.SweepTimeout (a VoError) instead of returning when the pair's disparity is undefined -- a strip
+        hand-off inside its aggregation sweep gave up waiting on an oversubscribed GPU: no pose is ever derived from such a
+        pair.  The odometer's state is that of before the call (the frame is neither saved nor counted as skipped); the same
+        pair may be passed again, or the next one."""
         next_3d, next_disp, next_img = self.stereo.compute_3d(img_left, img_right,
                                                               preprocessed=self.preprocessed_frames)
         next_kps, next_desc = self.orb.detectAndCompute(next_img, self.feature_mask(next_disp))
@@ -143,6 +148,15 @@ class StereoOdometer:
             finally:
                 del self._specs[key]
 
+    def reset_lookahead(self):
+        """Collect and drop the pose steps begun ahead of time and the camera's unconsumed look-ahead pairs (they are
+        recomputed when asked for).  Not in the reference: lets a caller start a measurement, or hand the camera to another
+        odometer, with nothing in flight."""
+        if self._ctx is not None:
+            self._drop_specs()
+        if hasattr(self.stereo, "reset_lookahead"):
+            self.stereo.reset_lookahead()
+
     def _start_next_pose(self):
         """The frame just accepted is the new `current`.  The pairs that will come next may already be on the device
         (look-ahead / submitted ahead): for as many of them as have FINISHED their disparity and keypoints (never waiting for
@@ -167,7 +181,10 @@ class StereoOdometer:
             if key not in self._ahead_counts:
                 if len(self._ahead_counts) > 64:
                     self._ahead_counts.clear()
-                self._ahead_counts[key] = self._ctx.orb_slot_count(s, *self.orb.last_slot_args)   # (finished: only collects the count)
+                try:
+                    self._ahead_counts[key] = self._ctx.orb_slot_count(s, *self.orb.last_slot_args)   # (finished: only collects the count)
+                except _native.VoError:
+                    self._ahead_counts[key] = -1     # that pair's own update() reports what is wrong with it; nothing is begun on it here
             counts.append(self._ahead_counts[key])
         params = self._pose_params()
         sk = self.stereo.slot_key       # slot + generation: a slot refilled with another pair never matches

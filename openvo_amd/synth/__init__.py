@@ -22,8 +22,23 @@ class _Cfg(ctypes.Structure):
 
 def build_synth(force=False):
     src = os.path.join(_HERE, "corridor.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-fopenmp", "-o", _LIB, src, "-lm"])
+
+    def stale():
+        return force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src)
+
+    if stale():
+        # several ranks of one job may get here together: one builds (into a temporary name, renamed when complete, so that
+        # nobody ever loads a half-written library), the others wait on the lock and find the library up to date
+        import fcntl
+        with open(_LIB + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    tmp = "%s.%d.tmp" % (_LIB, os.getpid())
+                    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-fopenmp", "-o", tmp, src, "-lm"])
+                    os.replace(tmp, _LIB)
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return _LIB
 
 

@@ -1,4 +1,5 @@
-"""Generate golden vectors from the REFERENCE's own numpy-only code.
+"""Generate golden vectors from the REFERENCE's own numpy-only code (G7 / G8 added in
+round 4: every decision point_clouds and point_cloud_transform make, with scripted stand-ins where they call cv2).
 
 Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
 The reference's heavy arithmetic lives in cv2, which is absent here; the functions exercised
@@ -212,6 +213,185 @@ def g6_rot2rpy():
     np.savez(os.path.join(HERE, "g6_rot2rpy.npz"), T=np.array(Ts), rpy=np.array(outs))
 
 
+# ---- G7: point_clouds (reference stereo_odometer.py:162-175) with a scripted matcher -----------------------------------------
+class _KP:
+    def __init__(self, x, y):
+        self.pt = (x, y)
+
+
+class _DM:
+    def __init__(self, q, t, d):
+        self.queryIdx, self.trainIdx, self.distance = int(q), int(t), float(d)
+
+
+class _Matcher:
+    """matcher.knnMatch(desc1, desc2, k=2) stand-in: hands back a prepared table (control flow only, no arithmetic)."""
+
+    def __init__(self, table):
+        self.table, self.calls = table, []
+
+    def knnMatch(self, d1, d2, k=2):
+        self.calls.append((d1, d2, k))
+        return self.table
+
+
+def g7_point_clouds():
+    rng = np.random.default_rng(707)
+    h, w = 40, 56
+    im1 = (rng.normal(size=(h, w, 3)) * 5 + [0, 0, 12]).astype(np.float32)
+    im2 = (rng.normal(size=(h, w, 3)) * 5 + [0, 0, 12]).astype(np.float32)
+    im1[7, 9] = np.inf                       # an inf tap next to a keypoint: excluded from the weights, not an error
+    im2[20, 30] = [np.inf, 1.0, 2.0]
+    out = dict(im1=im1, im2=im2)
+    cases = {}
+
+    def table_edges():
+        # (best, second) distance pairs at and around best == ratio * second, for every second distance 5 .. 255
+        rows = []
+        for d1 in range(5, 256, 5):
+            for off in (-1, 0, 1):
+                rows.append((round(0.8 * d1) + off, d1))
+        rows += [(0, 0), (0, 1), (1, 1), (255, 256), (204, 255), (205, 256), (3, 4), (2, 3)]
+        return rows
+
+    def run(name, rows, nq_extra=0, **kw):
+        n = len(rows)
+        kp1 = [(float(np.float32(rng.uniform(0, w - 1.001))), float(np.float32(rng.uniform(0, h - 1.001)))) for _ in range(n)]
+        ntrain = n + 7
+        kp2 = [(float(np.float32(rng.uniform(0, w - 1.001))), float(np.float32(rng.uniform(0, h - 1.001)))) for _ in range(ntrain)]
+        if n > 3:
+            kp1[0] = (8.5, 6.5)              # the cell with the inf tap of im1
+            kp1[3] = (55.0, 39.0)            # the last pixel: no right / lower neighbour
+        train = rng.permutation(ntrain)[:n]
+        second = (train + 1 + rng.integers(0, ntrain - 1, n)) % ntrain
+        table = [(_DM(i, train[i], rows[i][0]), _DM(i, second[i], rows[i][1])) for i in range(n)]
+        od = new_odom(**kw)
+        od.matcher = _Matcher(table)
+        real_bilinear, seen = od.bilinear_interpolate_pixels, []
+
+        def bilinear(img, x, y, _f=real_bilinear, _s=seen):          # which image was sampled where, in call order
+            _s.append((1 if img is im1 else 2, x, y))
+            return _f(img, x, y)
+
+        od.bilinear_interpolate_pixels = bilinear
+        with np.errstate(all="ignore"):
+            p1, p2 = od.point_clouds([_KP(*p) for p in kp1], [_KP(*p) for p in kp2], "desc1", "desc2", im1, im2)
+        assert od.matcher.calls == [("desc1", "desc2", 2)]
+        # the surviving matches, recovered from the coordinates the reference sampled (every keypoint position is unique)
+        q_idx = [kp1.index((x, y)) for (im, x, y) in seen if im == 1]
+        t_idx = [kp2.index((x, y)) for (im, x, y) in seen if im == 2]
+        assert [im for (im, _, _) in seen] == [1, 2] * len(q_idx)
+        c = dict(q_idx=np.array(q_idx, np.int64), t_idx=np.array(t_idx, np.int64),rows=np.array(rows, np.float64), train=train.astype(np.int64), second=second.astype(np.int64),
+                 kp1=np.array(kp1, np.float32), kp2=np.array(kp2, np.float32), none=np.array(p1 is None),
+                 match_threshold=np.float64(od.match_threshold), min_matches=np.int64(od.min_matches))
+        if p1 is not None:
+            assert p1.dtype == np.float32 and p2.dtype == np.float32, (p1.dtype, p2.dtype)
+            c["pts1"], c["pts2"] = p1, p2
+        cases[name] = c
+
+    run("edges_default", table_edges())
+    run("edges_thr07", [(round(0.7 * d1) + off, d1) for d1 in range(10, 200, 10) for off in (-1, 0, 1)], match_threshold=0.7)
+    rows9 = [(10, 50)] * 9 + [(40, 50)] * 6          # nine survivors of fifteen: one short of min_matches
+    run("nine_survivors", rows9)
+    run("ten_survivors", rows9 + [(39, 50)])
+    run("min_matches_5", [(10, 50)] * 5 + [(45, 50)] * 3, min_matches=5)
+    run("min_matches_5_short", [(10, 50)] * 4 + [(45, 50)] * 3, min_matches=5)
+    run("no_matches", [])
+    for name, c in cases.items():
+        for k, v in c.items():
+            out["%s__%s" % (name, k)] = v
+    np.savez(os.path.join(HERE, "g7_point_clouds.npz"), **out)
+
+
+# ---- G8: point_cloud_transform (reference stereo_odometer.py:177-223) with scripted cv2.estimateAffine3D / cv2.Rodrigues -------
+def g8_point_cloud_transform():
+    rng = np.random.default_rng(808)
+
+    def T34(t, ang=0.0):
+        c, s = np.cos(ang), np.sin(ang)
+        return np.array([[c, 0, s, t[0]], [0, 1, 0, t[1]], [-s, 0, c, t[2]]], np.float64)
+
+    def cloud(m, n_bad=0, noise=0.002):
+        prev = (rng.uniform(-4, 4, size=(m, 3)) * [1, 0.3, 3] + [0, 0, 12]).astype(np.float32)
+        cur = (prev + [0.01, 0.0, -0.25] + rng.normal(scale=noise, size=(m, 3))).astype(np.float32)
+        if n_bad:
+            bad = rng.choice(m, n_bad, replace=False)
+            cur[bad] += rng.normal(scale=2.0, size=(n_bad, 3)).astype(np.float32)
+        return prev, cur
+
+    good = T34([0.01, 0.0, -0.25], 0.01)
+    nanT = good.copy(); nanT[1, 2] = np.nan
+    third = np.pi / 3
+    cases = [
+        # name, odometer kwargs, skipped_frames, (prev, cur), transforms estimateAffine3D hands back in call order, Rodrigues vector
+        ("defaults_ok", {}, 0, cloud(40), [good], [0, 0.01, 0]),
+        ("defaults_7pts_min5", dict(min_matches=5), 0, cloud(7), [good], [0, 0.01, 0]),         # < 10 points: "rigidity" is set AND T returned
+        ("defaults_7pts", {}, 0, cloud(7), [], [0, 0, 0]),                                      # < 10 points, < min_matches: None, "rigidity"
+        ("rigid_ok", dict(rigidity_threshold=0.1), 0, cloud(60, 12), [good], [0, 0.01, 0]),
+        ("rigid_too_few", dict(rigidity_threshold=0.02), 0, cloud(14, 9, noise=0.0005), [], [0, 0, 0]),
+        ("rigid_9_min5", dict(rigidity_threshold=0.02, min_matches=5), 0, cloud(15, 6, noise=0.0005), [good], [0, 0.01, 0]),
+        ("outlier_ok", dict(outlier_threshold=0.02), 0, cloud(50, 8), [good, T34([0.011, 0, -0.251], 0.0101)], [0, 0.0101, 0]),
+        ("outlier_too_few", dict(outlier_threshold=0.0001), 0, cloud(12, 0, noise=0.05), [T34([3.0, 0, 0])], [0, 0, 0]),
+        ("rigid_then_outlier", dict(rigidity_threshold=0.1, outlier_threshold=0.02), 0, cloud(80, 20), [good, good], [0, 0.01, 0]),
+        ("nan", {}, 0, cloud(30), [nanT], [0, 0, 0]),
+        ("bigdist_s0", {}, 0, cloud(30), [T34([0.9, 0.0, 1.2])], [0, 0.2, 0]),                   # |t| = 1.5 > 1
+        ("bigdist_s2_passes", {}, 2, cloud(30), [T34([0.9, 0.0, 1.2])], [0, 0.2, 0]),            # 1.5 <= 3
+        ("bigdist_s2_fails", {}, 2, cloud(30), [T34([3.0, 0.0, 0.5])], [0, 0.2, 0]),
+        ("bigrot_s0", {}, 0, cloud(30), [T34([0.1, 0, 0.2], 1.2)], [0, 1.2, 0]),
+        ("bigrot_s2_passes", {}, 2, cloud(30), [T34([0.1, 0, 0.2], 1.2)], [0, 1.2, 0]),
+        ("bigrot_s2_fails", {}, 2, cloud(30), [T34([0.1, 0, 0.2], 3.15)], [0.1, 3.15, 0]),
+        ("both_gates", {}, 0, cloud(30), [T34([2.0, 0, 0], 1.3)], [0, 1.3, 0]),                  # "bigrot" is written last
+        ("dist_exactly_1", {}, 0, cloud(30), [T34([0.6, 0.0, 0.8])], [0, 0, 0]),                 # |t| == 1.0: not > 1
+        ("rot_exactly_limit", {}, 0, cloud(30), [T34([0, 0, 0.1])], [third, 0, 0]),              # == pi/3: not >
+        ("rot_just_over", {}, 0, cloud(30), [T34([0, 0, 0.1])], [np.nextafter(third, 4), 0, 0]),
+        ("rigid_cause_then_bigdist", dict(min_matches=5), 1, cloud(8), [T34([2.5, 0, 0])], [0, 0, 0]),   # "rigidity" overwritten by "bigdist"
+    ]
+    out = {}
+    for name, kw, skipped, (prev, cur), Ts, rvec in cases:
+        od = new_odom(**kw)
+        od.skipped_frames = skipped
+        od.skip_cause = "init"
+        queue, est_lens, rod_calls, masks = list(Ts), [], [], []
+
+        def estimate(src, dst, force_rotation=False, _q=queue, _l=est_lens):
+            assert force_rotation is True and len(src) == len(dst)
+            _l.append(len(src))
+            return _q.pop(0).copy(), 1.0
+
+        def rodrigues(R, _r=rvec, _c=rod_calls):
+            _c.append(np.array(R))
+            return np.array(_r, np.float64).reshape(3, 1), None
+
+        cv2.estimateAffine3D, cv2.Rodrigues = estimate, rodrigues
+        real_filter = od.rigid_body_filter
+
+        def rigid(a, b, _m=masks):
+            m = real_filter(a, b)
+            _m.append(np.asarray(m))
+            return m
+
+        od.rigid_body_filter = rigid
+        with np.errstate(all="ignore"):
+            ret = od.point_cloud_transform(prev.copy(), cur.copy())
+        assert not queue, name                       # every scripted transform was asked for
+        del cv2.estimateAffine3D, cv2.Rodrigues
+        pre = name + "__"
+        out[pre + "prev"], out[pre + "cur"] = prev, cur
+        out[pre + "kw"] = np.array([kw.get("rigidity_threshold", 0), kw.get("outlier_threshold", 0), kw.get("min_matches", 10), skipped], np.float64)
+        out[pre + "Ts"] = np.array(Ts, np.float64).reshape(-1, 3, 4)
+        out[pre + "rvec"] = np.array(rvec, np.float64)
+        out[pre + "ret_none"] = np.array(ret is None)
+        if ret is not None:
+            out[pre + "ret"] = np.asarray(ret, np.float64)
+        out[pre + "skip_cause"] = np.array(od.skip_cause)
+        out[pre + "est_lens"] = np.array(est_lens, np.int64)       # points handed to each estimateAffine3D call
+        out[pre + "n_rodrigues"] = np.array(len(rod_calls))
+        out[pre + "mask"] = masks[0] if masks else np.zeros(0, np.int64)
+    out["names"] = np.array([c[0] for c in cases])
+    np.savez(os.path.join(HERE, "g8_point_cloud_transform.npz"), **out)
+
+
 if __name__ == "__main__":
     g1_feature_mask(); g2_bilinear(); g3_rigid(); g4_outlier(); g5_state_machine(); g6_rot2rpy()
+    g7_point_clouds(); g8_point_cloud_transform()
     print("golden fixtures written to", HERE)

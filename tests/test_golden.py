@@ -117,3 +117,184 @@ def test_g6_rot2rpy():
             r, p, y = rot2RPY(T)
         assert r.shape == (2, 1)
         assert np.allclose(np.hstack([r, p, y]), exp, atol=1e-12, equal_nan=True)
+
+
+# ---- G7 / G8: every decision of point_clouds / point_cloud_transform, pinned by the reference run with scripted cv2 stand-ins ----
+def _g7_cases():
+    g = np.load(os.path.join(GOLD, "g7_point_clouds.npz"))
+    names = sorted({k.split("__")[0] for k in g.files if "__" in k})
+    assert names == ["edges_default", "edges_thr07", "min_matches_5", "min_matches_5_short", "nine_survivors", "no_matches",
+                     "ten_survivors"]
+    return g, names
+
+
+def _g7_table(g, name):
+    """(idx, dist) in the layout of a kNN-2 result: row i = query i, columns = best, second"""
+    rows, train, second = g[name + "__rows"].reshape(-1, 2), g[name + "__train"], g[name + "__second"]
+    idx = np.stack([train, second], 1).astype(np.int32).reshape(-1, 2)
+    return idx, rows.astype(np.int32)
+
+
+def test_g7_ratio_test_native_and_oracle(oracle):
+    """The strict `<` of the ratio test, on float32 distances against a double product (stereo_odometer.py:164): the
+    library's vo_ratio_filter and the oracle's keep exactly the matches the reference kept, in its order."""
+    import ctypes
+    from openvo_amd import _native
+    g, names = _g7_cases()
+    L = _native.lib()
+    n_checked = 0
+    for name in names:
+        idx, dist = _g7_table(g, name)
+        thr = float(g[name + "__match_threshold"])
+        if len(idx) == 0:
+            continue
+        want_q, want_t = g[name + "__q_idx"], g[name + "__t_idx"]
+        if bool(g[name + "__none"]):
+            want_n = None                      # the reference returned before sampling: only the count is observable (< min_matches)
+        else:
+            want_n = len(want_q)
+        q = np.zeros(len(idx), np.int32); t = np.zeros(len(idx), np.int32); m = ctypes.c_int(0)
+        assert L.vo_ratio_filter(idx.ctypes.data_as(ctypes.c_void_p), dist.ctypes.data_as(ctypes.c_void_p), len(idx), ctypes.c_double(thr),
+                                 q.ctypes.data_as(ctypes.c_void_p), t.ctypes.data_as(ctypes.c_void_p), ctypes.byref(m)) == 0
+        oq, ot = oracle.ratio_filter(idx, dist, thr)
+        assert np.array_equal(oq, q[:m.value]) and np.array_equal(ot, t[:m.value]), name
+        if want_n is None:
+            assert m.value < int(g[name + "__min_matches"]), name
+        else:
+            assert m.value == want_n and np.array_equal(q[:m.value], want_q) and np.array_equal(t[:m.value], want_t), name
+            n_checked += want_n
+    assert n_checked > 80
+
+
+def test_g7_point_clouds_oracle(oracle, monkeypatch):
+    """oracle/odometer.py's point_clouds on the scripted match tables: same None / arrays, same query -> frame 1 and
+    train -> frame 2 mapping, 3-D points bit-exact (stereo_odometer.py:162-175)."""
+    from oracle import oracle as O
+    from oracle.odometer import RefStereoOdometer
+    g, names = _g7_cases()
+    im1, im2 = g["im1"], g["im2"]
+
+    class Dense:
+        def __init__(self, a):
+            self.a = a
+
+        def sample(self, xy):
+            return O.bilinear_at(self.a, xy)
+
+    for name in names:
+        idx, dist = _g7_table(g, name)
+        monkeypatch.setattr(O, "bf_knn2_hamming", lambda a, b, _i=idx, _d=dist: (_i, _d))
+        od = RefStereoOdometer(None, match_threshold=float(g[name + "__match_threshold"]), min_matches=int(g[name + "__min_matches"]))
+        f1 = dict(desc="desc1", d3=Dense(im1), kps=dict(xy=g[name + "__kp1"].reshape(-1, 2)))
+        f2 = dict(desc="desc2", d3=Dense(im2), kps=dict(xy=g[name + "__kp2"].reshape(-1, 2)))
+        p1, p2 = od.point_clouds(f1, f2)
+        if bool(g[name + "__none"]):
+            assert p1 is None and p2 is None, name
+        else:
+            assert np.array_equal(od.last_matches[0], g[name + "__q_idx"]) and np.array_equal(od.last_matches[1], g[name + "__t_idx"]), name
+            for got, want in ((p1, g[name + "__pts1"]), (p2, g[name + "__pts2"])):
+                assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+
+
+def _g8_cases():
+    g = np.load(os.path.join(GOLD, "g8_point_cloud_transform.npz"))
+    names = [str(n) for n in g["names"]]
+    assert len(names) == 21 and {str(g[n + "__skip_cause"]) for n in names} == {"init", "rigidity", "outlier", "nan", "bigdist", "bigrot"}
+    return g, names
+
+
+def _g8_expect(g, n, ret, skip_cause, ctx):
+    assert (ret is None) == bool(g[n + "__ret_none"]), ctx
+    assert skip_cause == str(g[n + "__skip_cause"]), ctx
+    if ret is not None:
+        assert np.array_equal(np.asarray(ret), g[n + "__ret"]), ctx
+
+
+class _CtxStub:
+    def __init__(self, rvec):
+        self.rvec, self.n_rodrigues = np.asarray(rvec, np.float64), 0
+
+    def rodrigues(self, R):
+        self.n_rodrigues += 1
+        return self.rvec.copy()
+
+
+def test_g8_point_cloud_transform_host_generic_path():
+    """openvo_amd.StereoOdometer.point_cloud_transform through its public seams (estimate / rigid filter / Rodrigues handed
+    back from the fixture): rigidity < 10 vs "outlier" precedence, the quirk that "rigidity" is set while a T is still
+    returned when min_matches < 10, nan, both gates at skipped_frames 0 / 1 / 2, "bigrot" written after "bigdist", the
+    strict `>` of both gates -- decision for decision what the reference did (stereo_odometer.py:177-223)."""
+    from openvo_amd import StereoOdometer
+    g, names = _g8_cases()
+    for n in names:
+        rig, out, mm, skipped = g[n + "__kw"]
+        od = StereoOdometer(None, rigidity_threshold=float(rig), outlier_threshold=float(out), min_matches=int(mm))
+        od.skipped_frames, od.skip_cause = int(skipped), "init"
+        od._ctx = _CtxStub(g[n + "__rvec"])
+        queue, lens = [T for T in g[n + "__Ts"]], []
+
+        def estimate(src, dst, _q=queue, _l=lens):
+            _l.append(len(src))
+            return np.vstack([_q.pop(0), [0, 0, 0, 1]])
+
+        od._estimate = estimate
+        od.rigid_body_filter = lambda a, b, _m=g[n + "__mask"]: _m
+        with np.errstate(all="ignore"):
+            ret = od.point_cloud_transform(g[n + "__prev"].copy(), g[n + "__cur"].copy())
+        _g8_expect(g, n, ret, od.skip_cause, n)
+        assert lens == g[n + "__est_lens"].tolist() and not queue, n              # same fits on the same number of points
+        assert od._ctx.n_rodrigues == int(g[n + "__n_rodrigues"]), n
+
+
+def test_g8_fused_path_decision_table():
+    """_pair_fused turns the native step's record (M, n1, n2, flags, fit statuses, T) into the reference's decisions: fed
+    with the counts the reference run produced, it returns the same T / None and leaves the same skip_cause."""
+    from openvo_amd import StereoOdometer
+    g, names = _g8_cases()
+
+    class Stereo:
+        def slot_key(self, s):
+            return (s, 0)
+
+    for n in names:
+        rig, out, mm, skipped = g[n + "__kw"]
+        mm = int(mm)
+        lens = g[n + "__est_lens"].tolist()
+        M = len(g[n + "__prev"])
+        n1 = int(g[n + "__mask"].sum()) if rig > 0 else M
+        ran_outlier = out > 0 and n1 >= 10
+        final_fit = len(lens) == (2 if ran_outlier else 1)
+        n2 = lens[-1] if final_fit else (mm - 1 if ran_outlier else n1)
+        Ts = g[n + "__Ts"]
+        od = StereoOdometer(None, rigidity_threshold=float(rig), outlier_threshold=float(out), min_matches=mm)
+        od.stereo, od.skipped_frames, od.skip_cause = Stereo(), int(skipped), "init"
+        stub = _CtxStub(g[n + "__rvec"])
+        rec = (np.array([M, n1, n2, 0], np.int32), np.array([0 if ran_outlier else 1, 0 if final_fit else 1], np.int32), None,
+               Ts[-1] if final_fit else np.zeros((3, 4)))
+        stub.pose_pair = lambda a, b, *params, _r=rec: _r
+        od._ctx = stub
+        if M < mm:
+            continue                                   # (point_clouds would have returned None first: not a case of this table)
+        with np.errstate(all="ignore"):
+            ret = od._pair_fused(0, 1)
+        _g8_expect(g, n, ret, od.skip_cause, n)
+        assert stub.n_rodrigues == int(g[n + "__n_rodrigues"]), n
+
+
+def test_g8_point_cloud_transform_oracle(monkeypatch):
+    """oracle/odometer.py's restatement of point_cloud_transform, same fixture (its cv2 replacements scripted)."""
+    from oracle import oracle as O
+    from oracle.odometer import RefStereoOdometer
+    g, names = _g8_cases()
+    for n in names:
+        rig, out, mm, skipped = g[n + "__kw"]
+        od = RefStereoOdometer(None, rigidity_threshold=float(rig), outlier_threshold=float(out), min_matches=int(mm))
+        od.skipped_frames, od.skip_cause = int(skipped), "init"
+        queue, lens = [T for T in g[n + "__Ts"]], []
+        monkeypatch.setattr(O, "umeyama", lambda s, d, fr=True, _q=queue, _l=lens: (_l.append(len(s)) or _q.pop(0), 1.0))
+        monkeypatch.setattr(O, "rodrigues", lambda R, _v=g[n + "__rvec"]: _v.copy())
+        monkeypatch.setattr(O, "rigid_clique", lambda a, b, thr, _m=g[n + "__mask"]: _m)
+        with np.errstate(all="ignore"):
+            ret = od.point_cloud_transform(g[n + "__prev"].copy(), g[n + "__cur"].copy())
+        _g8_expect(g, n, ret, od.skip_cause, n)
+        assert lens == g[n + "__est_lens"].tolist() and not queue, n

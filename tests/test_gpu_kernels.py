@@ -293,3 +293,50 @@ def test_odd_image_sizes_sgbm_and_orb(oracle, ctx_small, w, h, ndisp, mind):
     assert len(g["xy"]) == len(r["xy"]) > 50
     assert np.array_equal(g["xy"].view(np.uint32), r["xy"].view(np.uint32)) and np.array_equal(g["desc"], r["desc"])
     assert np.array_equal(g["angle"].view(np.uint32), r["angle"].view(np.uint32)) and np.array_equal(g["octave"], r["octave"])
+
+
+def test_point_clouds_generic_path_matches_reference_golden_g7():
+    """The product's point_clouds through its public seams -- a user-supplied matcher (here: the scripted kNN tables of
+    fixture G7), KeyPoint-like objects, host 3-D images -- against what the reference itself returned for the same
+    inputs: the strict `<` of the ratio test at and around ratio * second, min_matches, queryIdx -> frame 1 /
+    trainIdx -> frame 2, and the sampled points bit for bit (stereo_odometer.py:162-175)."""
+    from openvo_amd import StereoCamera, StereoOdometer
+    g = np.load(os.path.join(GOLD, "g7_point_clouds.npz"))
+    names = sorted({k.split("__")[0] for k in g.files if "__" in k})
+    c = Corridor("T0")
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=300)
+
+    class KP:
+        def __init__(self, xy):
+            self.pt = (float(xy[0]), float(xy[1]))
+
+    class DM:
+        def __init__(self, q, t, d):
+            self.queryIdx, self.trainIdx, self.distance = int(q), int(t), float(d)
+
+    class Matcher:
+        def __init__(self, table):
+            self.table = table
+
+        def knnMatch(self, d1, d2, k=2):
+            assert k == 2
+            return self.table
+
+    n_pts = 0
+    for name in names:
+        rows, train, second = g[name + "__rows"].reshape(-1, 2), g[name + "__train"], g[name + "__second"]
+        table = [(DM(i, train[i], rows[i][0]), DM(i, second[i], rows[i][1])) for i in range(len(rows))]
+        od = StereoOdometer(cam, match_threshold=float(g[name + "__match_threshold"]), min_matches=int(g[name + "__min_matches"]))
+        od.matcher = Matcher(table)
+        kp1 = [KP(p) for p in g[name + "__kp1"].reshape(-1, 2)]
+        kp2 = [KP(p) for p in g[name + "__kp2"].reshape(-1, 2)]
+        p1, p2 = od.point_clouds(kp1, kp2, "desc1", "desc2", g["im1"], g["im2"])
+        if bool(g[name + "__none"]):
+            assert p1 is None and p2 is None, name
+            continue
+        for got, want in ((p1, g[name + "__pts1"]), (p2, g[name + "__pts2"])):
+            got = np.asarray(got)
+            assert got.dtype == np.float32 and got.shape == want.shape, name
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+        n_pts += len(p1)
+    assert n_pts > 80

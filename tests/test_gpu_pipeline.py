@@ -460,11 +460,91 @@ def test_failed_prefetch_mid_stream_leaves_the_context_usable():
     assert r.returncode == 0 and "failed-prefetch body ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def _sweep_timeout_body():
+    """Body of test_sweep_timeout_raises_and_the_next_pair_is_exact: own process, test-only build of the library.
+    VO_FAULT_SWEEP=n makes the n-th diagonal sweep of the context export nothing and give up its waits after 64 polls: the
+    real failure path of an oversubscribed GPU (a strip hand-off that never arrives), forced."""
+    import os
+    from openvo_amd import _native
+    kw = dict(preprocessed_frames=True, rigidity_threshold=0.1, outlier_threshold=0.02)
+    c0, cam0 = _rig("C1", max_keypoints=500)
+    frames = c0.pairs(0, 10)
+    ref = StereoOdometer(cam0, **kw)
+    want = [(ref.update(L, R), ref.c_T_w.copy()) for L, R in frames]
+    assert cam0._ctx.sgbm_sweep_status() == 0
+
+    # (a) plain update() calls on host arrays: the 3rd pair's sweep fails
+    os.environ["VO_FAULT_SWEEP"] = "3"
+    c, cam = _rig("C1", max_keypoints=500)
+    odo = StereoOdometer(cam, **kw)
+    got, raised = [], 0
+    for k, (L, R) in enumerate(frames[:6]):
+        try:
+            ok = odo.update(L, R)
+        except _native.SweepTimeout as e:
+            assert e.code == _native.VO_E_SWEEP and k == 2, (k, str(e))
+            raised += 1
+            before = (odo.skipped_frames, odo.c_T_w.copy(), odo.current_kps)
+            ok = odo.update(L, R)                                  # the same pair again: exact now
+            assert before[0] == 0 and odo.current_kps is not before[2]
+        got.append((ok, odo.c_T_w.copy()))
+    assert raised == 1 and cam._ctx.sgbm_sweep_status() == 1
+    for (a, Ta), (b, Tb) in zip(got, want):
+        assert a == b and np.array_equal(Ta, Tb)
+    # the seam itself refuses the disparity too, and the one after it is exact again
+    os.environ["VO_FAULT_SWEEP"] = "1"
+    c3, cam3 = _rig("C1", max_keypoints=500)
+    with pytest.raises(_native.SweepTimeout):
+        cam3.stereoSGBM.compute(*frames[1])
+    assert np.array_equal(cam3.stereoSGBM.compute(*frames[1]), cam0.stereoSGBM.compute(*frames[1]))
+
+    # (b) staged pairs with the default look-ahead (pose steps begun ahead included): the 5th sweep = staged pair 4 fails while
+    # it runs AHEAD on an engine; update(4) raises -- not update(3), which only looked at it -- and passing pair 4 again works
+    os.environ["VO_FAULT_SWEEP"] = "5"
+    c2, cam2 = _rig("C1", max_keypoints=500)
+    del os.environ["VO_FAULT_SWEEP"]
+    staged = cam2.stage_pairs(frames)
+    odo2 = StereoOdometer(cam2, **kw)
+    got2, raised2 = [], []
+    for k in range(len(frames)):
+        try:
+            ok = odo2.update(staged[k], None)
+        except _native.SweepTimeout:
+            raised2.append(k)
+            ok = odo2.update(staged[k], None)
+        got2.append((ok, odo2.c_T_w.copy()))
+    assert raised2 == [4], raised2
+    assert cam2._ctx.sgbm_sweep_status() == 1
+    for (a, Ta), (b, Tb) in zip(got2, want):
+        assert a == b and np.array_equal(Ta, Tb)
+    print("sweep-timeout body ok")
+
+
+def test_sweep_timeout_raises_and_the_next_pair_is_exact():
+    """A strip hand-off of the diagonal aggregation sweep that gives up waiting leaves that pair's disparity undefined.
+    The product must say so -- update() raises SweepTimeout (VO_E_SWEEP), never returns a pose from it -- and the failure
+    must not outlive the pair: the launch's abort word is cleared by the workspace's next run, so the same pair submitted
+    again (and every later one) is bit-exact.  Forced through the test-only build (libvo355_hooks.so, VO_FAULT_SWEEP)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hooks = os.path.join(root, "openvo_amd", "libvo355_hooks.so")
+    assert os.path.exists(hooks), "build the test-only library first (__graft_entry__.build())"
+    env = dict(os.environ, VO355_LIB=hooks)
+    r = subprocess.run([sys.executable, "-c", "import tests.test_gpu_pipeline as t; t._sweep_timeout_body()"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sweep-timeout body ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_product_library_has_no_failure_injection(monkeypatch):
-    """The product build ignores VO_FAULT_PREFETCH: nothing a user's environment holds can make a submission fail."""
+    """The product build ignores VO_FAULT_PREFETCH / VO_FAULT_SWEEP: nothing a user's environment holds can make a submission
+    or a sweep fail."""
     monkeypatch.setenv("VO_FAULT_PREFETCH", "1")
+    monkeypatch.setenv("VO_FAULT_SWEEP", "1")
     c, cam = _rig("T0", max_keypoints=300)
     monkeypatch.delenv("VO_FAULT_PREFETCH")
+    monkeypatch.delenv("VO_FAULT_SWEEP")
     sp = [cam.submit(*c.pair(k), preprocessed=True) for k in range(3)]
     odo = StereoOdometer(cam, nfeatures=300, preprocessed_frames=True)
     assert odo.update(sp[0], None) is True
