@@ -23,7 +23,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")   # before any HIP runtime starts (see openvo_amd/__init__.py)
+# (GPU_MAX_HW_QUEUES is set by openvo_amd at import, before any HIP runtime starts: 24, or this process' share with VO_SHARE_GPU)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -93,13 +93,7 @@ def bench_stereo(args, group, device, workload, K, W, light):
     from openvo_amd import StereoCamera, StereoOdometer, sharding
     from openvo_amd.synth import Corridor
     rank, world = group.rank, group.world
-    ndev = sharding.device_count()
-    masked = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
-    if world > 1 and 0 < ndev < world and not masked:      # (a launcher that masks devices per rank gives each its own GPU)
-        # rehearsal with several ranks on one GPU: their hardware queues add up, so each takes its share of the engines
-        share = -(-world // ndev)
-        os.environ.setdefault("VO_ENGINES", str(max(2, 8 // share)))        # (2 x 6 engines on one GPU oversubscribe its hardware
-        os.environ.setdefault("VO_LOOKAHEAD", str(max(3, 10 // share)))     #  queues and the rate collapses; 2 x 4 is fine)
+    # (a rehearsal with several ranks on one GPU: VO_SHARE_GPU=<ranks per GPU> in the environment, read by openvo_amd at import)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -183,6 +177,7 @@ def bench_stereo(args, group, device, workload, K, W, light):
     # /root/reference/src/openVO/stereo_odometer.py:14-15) and a long steady-state pass -- neither is `value`
     dt_default = dt_steady = None
     steady_acc = 0
+    dodo = sodo = probe = None
     if not (light or args.no_post or args.from_host):
         kw = dict(ODO_KW, rigidity_threshold=0, outlier_threshold=0)
         dodo = StereoOdometer(cam, **kw)
@@ -236,6 +231,8 @@ def bench_stereo(args, group, device, workload, K, W, light):
         # of the staging thread and the pipeline's fill)
         nh = 96
         hframes = c.pairs(first + n_unique, 8 + nh)
+        # (the odometers of the earlier passes still own two frame slots each: give them back, the host path's look-ahead wants them)
+        odo = dodo = sodo = probe = None
         hodo = StereoOdometer(cam, **ODO_KW)
         cam.reset_lookahead()
         for ok in hodo.run(hframes[:8]):

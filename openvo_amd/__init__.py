@@ -7,11 +7,36 @@ libvo355.so (hand-written HIP for gfx950, C ABI in include/vo355.h); there is no
 """
 import os as _os
 
-# The look-ahead engines (6) and the ahead-of-time pose steps (3) run on their own HIP streams next to the
-# main one; the runtime multiplexes streams onto 4 hardware queues by default, which would serialise
-# whichever of them happen to share one.  Must be set before the
-# HIP runtime initialises (a process that has already created a HIP context keeps its own setting).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# The look-ahead engines (16) and the ahead-of-time pose steps (3 streams) run on their own HIP streams next to the main
+# one; the runtime multiplexes streams onto 4 hardware queues by default, which would serialise whichever of them happen
+# to share one.  Must be set before the HIP runtime initialises (a process that has already created a HIP context keeps its
+# own setting; an explicit GPU_MAX_HW_QUEUES in the environment is respected).
+#
+# The defaults assume the process has the GPU to itself.  A GPU's hardware queues are a shared, finite resource (about two
+# dozen before the scheduler starts time-slicing whole processes in ~10 ms quanta -- and the diagonal sweep's strips wait for
+# each other inside a launch, so a time-sliced sweep crawls): when several processes will drive ONE GPU, tell each of them
+# with VO_SHARE_GPU=<number of processes on that GPU> and it takes its share of the queues and sizes its engines to fit
+# (INTEGRATION.md section 3).  VO_ENGINES / VO_POSE_STREAMS / VO_LOOKAHEAD set explicitly win.
+def _queue_budget():
+    try:
+        share = int(_os.environ.get("VO_SHARE_GPU", "0") or 0)
+    except ValueError:
+        share = 0
+    if share == 1:
+        share = 2                      # (rounds 2-3 used VO_SHARE_GPU=1 as a yes / no switch for a two-rank rehearsal)
+    if share < 2:
+        _os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+        return
+    hwq = max(6, 24 // share)
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", str(hwq))
+    pose = 2 if hwq >= 10 else 1
+    engines = max(2, hwq - 2 - pose)   # one queue for the main stream, one spare
+    _os.environ.setdefault("VO_POSE_STREAMS", str(pose))
+    _os.environ.setdefault("VO_ENGINES", str(engines))
+    _os.environ.setdefault("VO_LOOKAHEAD", str(engines + 2))
+
+
+_queue_budget()
 
 from .stereo_camera import StereoCamera
 from .stereo_odometer import StereoOdometer

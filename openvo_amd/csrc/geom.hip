@@ -1371,7 +1371,7 @@ static int pose_alt_prepare(vo_ctx* ctx, int k)
     vo_ctx::PoseAlt& p = ctx->pose_alt[k];
     if (p.ready) return VO_OK;
     const size_t cap = (size_t)ctx->kp_cap;
-    hipStream_t& shared = ctx->pose_streams[k % vo_ctx::N_POSE_STREAMS];
+    hipStream_t& shared = ctx->pose_streams[k % ctx->n_pose_streams];
     if (!shared) VO_HIP(ctx, hipStreamCreateWithFlags(&shared, hipStreamNonBlocking));
     p.stream = shared;                            // (not owned by the alternate)
     VO_HIP(ctx, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
@@ -1438,8 +1438,7 @@ extern "C" int vo_pose_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
     if (rc) return rc;
     // both slots are read on this alternate's stream until p.done: whoever refills one of them waits for it first
     for (FrameSlot* f : { &a, &b }) {
-        if (f->readers[0] == p.done || f->readers[1] == p.done) continue;
-        f->readers[f->readers[0] ? 1 : 0] = p.done;
+        slot_add_reader(*f, p.done);
     }
     p.busy = true; p.slot_a = slot_a; p.slot_b = slot_b;
     p.gen_a = a.disp_gen; p.gen_b = b.disp_gen;

@@ -9,6 +9,7 @@
 // Pyramid layout in HBM: one byte buffer per kind (image, blurred, mask, FAST score), level l
 // stored tightly (stride = level width) at lv[l].off.
 #include <math.h>
+#include <algorithm>
 #include "vo_internal.h"
 
 #define NL VO_ORB_LEVELS
@@ -101,6 +102,50 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h)
         }
     }
     if (off > ctx->pyr_bytes) return vo_fail(ctx, VO_E_CAP, "pyramid of %dx%d exceeds the context capacity", w, h);
+    // k_orb_pyramid's cones: level l is cut into nbx x nby parts of equal share (part i owns columns [i w_l / nbx, (i+1) w_l / nbx));
+    // a cone also computes, per level, the margin the next level's interval reads (bilinear taps ofs[v], ofs[v] + 1), top-down
+    std::vector<int32_t> rects;
+    int pyr_nbx, pyr_nby, pyr_buf[2] = { 0, 0 }, pyr_tab = 0;
+    {
+        const LevelDev& top = L.l[NL - 1];
+        pyr_nbx = std::max(1, std::min({ div_up(w, 88), top.w / 8, 40 }));
+        pyr_nby = std::max(1, std::min({ div_up(h, 80), top.h / 8, 40 }));
+        auto intervals = [&](int nb, bool xaxis, std::vector<int32_t>& out) {     // out[l][b][2]
+            out.assign((size_t)NL * nb * 2, 0);
+            for (int b = 0; b < nb; b++) {
+                int nlo = 0, nhi = -1;                               // interval needed at the level above (empty at the top)
+                for (int l = NL - 1; l >= 0; l--) {
+                    const LevelDev& d = L.l[l];
+                    const int size = xaxis ? d.w : d.h;
+                    int lo = (int)((int64_t)b * size / nb), hi = (int)((int64_t)(b + 1) * size / nb) - 1;   // own part
+                    if (l < NL - 1 && nlo <= nhi) {
+                        const LevelDev& u = L.l[l + 1];
+                        const int32_t* o = ofs.data() + (xaxis ? u.xt : u.yt);
+                        const int mn = xaxis ? u.min_x : u.min_y, mx = xaxis ? u.max_x : u.max_y;
+                        const int slo = nlo < mn ? 0 : (nlo >= mx ? size - 1 : o[nlo]);
+                        const int shi = nhi < mn ? 0 : (nhi >= mx ? size - 1 : std::min(o[nhi] + 1, size - 1));
+                        if (lo > hi) { lo = slo; hi = shi; }
+                        else { lo = std::min(lo, slo); hi = std::max(hi, shi); }
+                    }
+                    out[((size_t)l * nb + b) * 2] = lo; out[((size_t)l * nb + b) * 2 + 1] = hi;
+                    nlo = lo; nhi = hi;
+                }
+            }
+        };
+        std::vector<int32_t> rx, ry;
+        intervals(pyr_nbx, true, rx);
+        intervals(pyr_nby, false, ry);
+        for (int l = 0; l < NL; l++) {
+            int mw = 0, mh = 0;
+            for (int b = 0; b < pyr_nbx; b++) mw = std::max(mw, rx[((size_t)l * pyr_nbx + b) * 2 + 1] - rx[((size_t)l * pyr_nbx + b) * 2] + 1);
+            for (int b = 0; b < pyr_nby; b++) mh = std::max(mh, ry[((size_t)l * pyr_nby + b) * 2 + 1] - ry[((size_t)l * pyr_nby + b) * 2] + 1);
+            pyr_buf[l & 1] = std::max(pyr_buf[l & 1], ((mw * mh + 15) & ~15));
+            if (l > 0) pyr_tab = std::max(pyr_tab, std::max(mw, mh));
+        }
+        rects = rx;
+        rects.insert(rects.end(), ry.begin(), ry.end());
+        if (rects.size() > 4096) return vo_fail(ctx, VO_E_CAP, "pyramid cone table exceeds its capacity");
+    }
     if ((size_t)cand_off > (size_t)ctx->cand_cap * 4) return vo_fail(ctx, VO_E_CAP, "candidate capacity exceeded");
     if (ofs.size() > (size_t)(ctx->max_w + ctx->max_h) * 2 * NL) return vo_fail(ctx, VO_E_CAP, "resize tables exceed capacity");
     // umax: row half-widths of the circular patch (orb.cpp computeKeyPoints)
@@ -125,7 +170,9 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h)
         if (ctx->mono_alt[k].stream) VO_HIP(ctx, hipStreamSynchronize(ctx->mono_alt[k].stream));
     VO_HIP(ctx, hipMemcpyAsync(ctx->rs_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     VO_HIP(ctx, hipMemcpyAsync(ctx->rs_coef, coef.data(), coef.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(ctx, hipMemcpyAsync(ctx->pyr_rects, rects.data(), rects.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pyr_nbx = pyr_nbx; ctx->pyr_nby = pyr_nby; ctx->pyr_buf[0] = pyr_buf[0]; ctx->pyr_buf[1] = pyr_buf[1]; ctx->pyr_tab = pyr_tab;
     static_assert(sizeof(LevelsDev) <= sizeof(ctx->rs_meta_host), "level table too large");
     memcpy(ctx->rs_meta_host, &L, sizeof(L));
     ctx->orb_quota_nfeatures = -1;
@@ -136,61 +183,110 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h)
 // ---------------------------------------------------------------------------------------
 // pyramid
 // ---------------------------------------------------------------------------------------
-// level 0 = the cropped left image; mask level 0 from the disparity range (feature_mask) or an
-// explicit mask
-__global__ void k_orb_level0(const uint8_t* __restrict__ img, int img_stride, int w, int h, int mask_mode,
-                             const int16_t* __restrict__ disp16, int disp_stride, int min_d16, int max_d16,
-                             const uint8_t* __restrict__ mask, int mask_stride, uint8_t* __restrict__ pimg,
-                             uint8_t* __restrict__ pmask, int32_t* __restrict__ cnt)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (blockIdx.x == 0 && y == 0 && threadIdx.x < CNT_HIST) cnt[threadIdx.x] = 0;   // the run's counters start here
-    if (x >= w) return;
-    pimg[(size_t)y * w + x] = img[(size_t)y * img_stride + x];
-    if (mask_mode == 1) {
-        int d = disp16[(size_t)y * disp_stride + x];
-        pmask[(size_t)y * w + x] = (d >= min_d16 && d <= max_d16) ? 255 : 0;
-    } else if (mask_mode == 2)
-        pmask[(size_t)y * w + x] = mask[(size_t)y * mask_stride + x];
-}
+// The whole pyramid in ONE launch (was: a copy kernel + seven resize launches, each level waiting for the one before).
+// resize(prev, cur, INTER_LINEAR_EXACT) makes level l a function of level l - 1, but only locally: output column v reads the
+// columns ofs[v], ofs[v] + 1 of the level below.  So the pyramid is cut into cones: workgroup (bx, by) owns part (bx, by) of
+// EVERY level and, per level, also computes the margin the next level's part reads (1 pixel at the top, growing by the scale
+// factor per level down: <= 13 pixels at level 0) -- the intervals are prepared by the host (orb_prepare_tables).  A cone's
+// levels live in two ping-pong LDS rectangles per image kind; the owned part of every level is written to the pyramid in
+// HBM.  Values are those of the level-by-level kernels bit for bit: the same fixed-point taps in the same order; border
+// columns / rows (v < min, v >= max: the clamped taps of the exact-bilinear table) become taps with weights (256, 0).
+// The mask pyramid (feature_mask of stereo_odometer.py:38-41 at level 0, or an explicit mask) is resized the same way and
+// then thresholded (threshold(254, THRESH_TOZERO)), as orb.cpp does.
+struct PyrArgs {
+    const uint8_t* img; const int16_t* disp16; const uint8_t* mask;
+    int img_stride, disp_stride, mask_stride, mask_mode, min_d16, max_d16, nbx, nby, bufA, bufB, tab;
+};
 
-__device__ __forceinline__ unsigned hrow(const uint8_t* __restrict__ s, int sw, int dx, const LevelDev& d,
-                                         const int32_t* __restrict__ xo, const uint16_t* __restrict__ xc)
+template <bool MASK>
+__global__ void __launch_bounds__(256) k_orb_pyramid(const LevelsDev L, const PyrArgs A, const int32_t* __restrict__ rects,
+                                                     const int32_t* __restrict__ ofs, const uint16_t* __restrict__ coef,
+                                                     uint8_t* __restrict__ pimg, uint8_t* __restrict__ pmask, int32_t* __restrict__ cnt)
 {
-    if (dx < d.min_x) return (unsigned)s[0] << 8;
-    if (dx >= d.max_x) return (unsigned)s[sw - 1] << 8;
-    const uint8_t* px = s + xo[dx];
-    return (unsigned)xc[2 * dx] * px[0] + (unsigned)xc[2 * dx + 1] * px[1];
-}
-
-// resize(prev, cur, INTER_LINEAR_EXACT) for image and (optionally) mask; mask then
-// threshold(254, THRESH_TOZERO)
-__global__ void k_orb_resize(const LevelsDev L, int lvl, const int32_t* __restrict__ ofs,
-                             const uint16_t* __restrict__ coef, uint8_t* __restrict__ pimg, uint8_t* __restrict__ pmask,
-                             int with_mask)
-{
-    const LevelDev d = L.l[lvl];
-    const LevelDev p = L.l[lvl - 1];
-    int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
-    if (dx >= d.w) return;
-    const int32_t* xo = ofs + d.xt;
-    const uint16_t* xc = coef + 2 * (size_t)d.xt;
-    const int32_t* yo = ofs + d.yt;
-    const uint16_t* yc = coef + 2 * (size_t)d.yt;
-    for (int pass = 0; pass < (with_mask ? 2 : 1); pass++) {
-        const uint8_t* src = (pass ? pmask : pimg) + p.off;
-        uint8_t* dst = (pass ? pmask : pimg) + d.off;
-        unsigned out;
-        if (dy < d.min_y || dy >= d.max_y) {
-            const uint8_t* s = src + (size_t)(dy < d.min_y ? 0 : p.h - 1) * p.w;
-            out = (hrow(s, p.w, dx, d, xo, xc) + 128u) >> 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_pyr[];
+    // [img even | img odd | mask even | mask odd | x taps: o0, o1 (u16) c0, c1 (u16) | y taps]
+    uint8_t* const bimg[2] = { s_pyr, s_pyr + A.bufA };
+    uint8_t* const bmsk[2] = { s_pyr + A.bufA + A.bufB, s_pyr + 2 * A.bufA + A.bufB };
+    uint16_t* const tx = (uint16_t*)(s_pyr + (MASK ? 2 : 1) * (A.bufA + A.bufB));     // [tab][4]
+    uint16_t* const ty = tx + 4 * A.tab;
+    const int bx = blockIdx.x, by = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (bx == 0 && by == 0 && threadIdx.x < CNT_HIST) cnt[threadIdx.x] = 0;           // the run's counters start here
+    const int32_t* const rxs = rects;
+    const int32_t* const rys = rects + NL * A.nbx * 2;
+    int px0 = 0, py0 = 0, pnw = 0;                                                    // rectangle of the level below (origin, pitch)
+    for (int l = 0; l < NL; l++) {
+        const LevelDev d = L.l[l];
+        const int x0 = rxs[(l * A.nbx + bx) * 2], x1 = rxs[(l * A.nbx + bx) * 2 + 1];
+        const int y0 = rys[(l * A.nby + by) * 2], y1 = rys[(l * A.nby + by) * 2 + 1];
+        const int nw = x1 - x0 + 1, nh = y1 - y0 + 1;
+        const int ox0 = (int)((long long)bx * d.w / A.nbx), ox1 = (int)((long long)(bx + 1) * d.w / A.nbx);     // owned part [ox0, ox1)
+        const int oy0 = (int)((long long)by * d.h / A.nby), oy1 = (int)((long long)(by + 1) * d.h / A.nby);
+        uint8_t* const di = bimg[l & 1];
+        uint8_t* const dm = bmsk[l & 1];
+        if (l == 0) {
+            for (int yy = wv; yy < nh; yy += 4) {
+                const int y = y0 + yy;
+                for (int xx = lane; xx < nw; xx += 64) {
+                    const int x = x0 + xx;
+                    const uint8_t v = A.img[(size_t)y * A.img_stride + x];
+                    di[yy * nw + xx] = v;
+                    const bool own = x >= ox0 && x < ox1 && y >= oy0 && y < oy1;
+                    if (own) pimg[(size_t)y * d.w + x] = v;
+                    if (MASK) {
+                        uint8_t m;
+                        if (A.mask_mode == 1) {
+                            const int dd = A.disp16[(size_t)y * A.disp_stride + x];
+                            m = (dd >= A.min_d16 && dd <= A.max_d16) ? 255 : 0;
+                        } else
+                            m = A.mask[(size_t)y * A.mask_stride + x];
+                        dm[yy * nw + xx] = m;
+                        if (own) pmask[(size_t)y * d.w + x] = m;
+                    }
+                }
+            }
         } else {
-            const uint8_t* s0 = src + (size_t)yo[dy] * p.w;
-            unsigned h0 = hrow(s0, p.w, dx, d, xo, xc), h1 = hrow(s0 + p.w, p.w, dx, d, xo, xc);
-            out = (h0 * (unsigned)yc[2 * dy] + h1 * (unsigned)yc[2 * dy + 1] + 32768u) >> 16;
+            const LevelDev p = L.l[l - 1];
+            // this level's taps, relative to the rectangle of the level below: {o0, o1, c0, c1} per column / row
+            for (int i = threadIdx.x; i < nw + nh; i += blockDim.x) {
+                const bool isx = i < nw;
+                const int v = isx ? x0 + i : y0 + (i - nw);
+                const int mn = isx ? d.min_x : d.min_y, mx = isx ? d.max_x : d.max_y, t0 = isx ? d.xt : d.yt;
+                const int ssz = isx ? p.w : p.h, org = isx ? px0 : py0;
+                int o0, o1, c0 = 256, c1 = 0;
+                if (v < mn) o0 = o1 = 0;
+                else if (v >= mx) o0 = o1 = ssz - 1;
+                else { o0 = ofs[t0 + v]; o1 = o0 + 1; c0 = coef[2 * (size_t)(t0 + v)]; c1 = coef[2 * (size_t)(t0 + v) + 1]; }
+                uint16_t* t = (isx ? tx + 4 * i : ty + 4 * (i - nw));
+                t[0] = (uint16_t)(o0 - org); t[1] = (uint16_t)(o1 - org); t[2] = (uint16_t)c0; t[3] = (uint16_t)c1;
+            }
+            __syncthreads();
+            const uint8_t* const si = bimg[(l - 1) & 1];
+            const uint8_t* const sm = bmsk[(l - 1) & 1];
+            for (int yy = wv; yy < nh; yy += 4) {
+                const int y = y0 + yy;
+                const unsigned r0 = ty[4 * yy] * (unsigned)pnw, r1 = ty[4 * yy + 1] * (unsigned)pnw, yc0 = ty[4 * yy + 2], yc1 = ty[4 * yy + 3];
+                for (int xx = lane; xx < nw; xx += 64) {
+                    const int x = x0 + xx;
+                    const unsigned a0 = tx[4 * xx], a1 = tx[4 * xx + 1], xc0 = tx[4 * xx + 2], xc1 = tx[4 * xx + 3];
+                    const bool own = x >= ox0 && x < ox1 && y >= oy0 && y < oy1;
+                    {
+                        const unsigned h0 = xc0 * si[r0 + a0] + xc1 * si[r0 + a1], h1 = xc0 * si[r1 + a0] + xc1 * si[r1 + a1];
+                        const unsigned out = (h0 * yc0 + h1 * yc1 + 32768u) >> 16;
+                        di[yy * nw + xx] = (uint8_t)out;
+                        if (own) pimg[d.off + (size_t)y * d.w + x] = (uint8_t)out;
+                    }
+                    if (MASK) {
+                        const unsigned h0 = xc0 * sm[r0 + a0] + xc1 * sm[r0 + a1], h1 = xc0 * sm[r1 + a0] + xc1 * sm[r1 + a1];
+                        unsigned out = (h0 * yc0 + h1 * yc1 + 32768u) >> 16;
+                        out = out > 254u ? out : 0u;
+                        dm[yy * nw + xx] = (uint8_t)out;
+                        if (own) pmask[d.off + (size_t)y * d.w + x] = (uint8_t)out;
+                    }
+                }
+            }
         }
-        if (pass) out = out > 254u ? out : 0u;
-        dst[(size_t)dy * d.w + dx] = (uint8_t)out;
+        px0 = x0; py0 = y0; pnw = nw;
+        __syncthreads();
     }
 }
 
@@ -321,46 +417,60 @@ __global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev L, const u
     }
 }
 
-// retainBest(2*quota) by FAST score: keep every candidate whose score >= the n-th largest
+// retainBest(2*quota) by FAST score: keep every candidate whose score >= the n-th largest.  The survivors go to `lds_pos`
+// when all of them fit (lds_cap entries; the fused kernel), to outA otherwise; s_inlds says which.
 __device__ __forceinline__ void orb_fast_select(const LevelsDev& L, const int32_t* cand_pos,
-                                                const float* cand_resp, int32_t* candA_pos,
-                                                int32_t* cnt, int* s_hist, int& s_thr, int& s_n)
+                                                const float* cand_resp, int32_t* outA,
+                                                int32_t* cnt, int* s_hist, int& s_thr, int& s_n, int32_t* lds_pos, int lds_cap, int& s_inlds)
 {
     const int lvl = blockIdx.x;
     const LevelDev d = L.l[lvl];
     const int n = cnt[CNT_CAND + lvl], keep = 2 * d.quota;
     const int32_t* pos = cand_pos + d.cand_off;
     const float* resp = cand_resp + d.cand_off;
+    const int nt = blockDim.x;
     // histogram of the (integer) FAST scores in LDS
-    for (int b = threadIdx.x; b < 256; b += blockDim.x) s_hist[b] = 0;
+    for (int b = threadIdx.x; b < 256; b += nt) s_hist[b] = 0;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     if (keep > 0 && n > keep)
-        for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_hist[(int)resp[i] & 255], 1);
+        for (int i0 = threadIdx.x; i0 < n; i0 += 4 * nt) {         // four loads in flight per thread: the list is long, the block alone
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = i0 + k * nt < n ? resp[i0 + k * nt] : -1.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (r[k] >= 0.f) atomicAdd(&s_hist[(int)r[k] & 255], 1);
+        }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int thr = 0;
-        if (keep == 0) thr = 1 << 30;
+        int thr = 0, kept = n;
+        if (keep == 0) { thr = 1 << 30; kept = 0; }
         else if (n > keep) {
             int cum = 0;
             for (int b = 255; b >= 0; b--) {
                 cum += s_hist[b];
                 if (cum >= keep) { thr = b; break; }
             }
+            kept = cum;
         }
         s_thr = thr;
+        s_inlds = lds_pos != nullptr && kept <= lds_cap;
     }
     __syncthreads();
     const int thr = s_thr;
+    int32_t* const dst = s_inlds ? lds_pos : outA + d.cand_off;
     const int lane = threadIdx.x & 63;
-    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
-        const int i = i0 + threadIdx.x;
-        const bool keepit = i < n && (int)resp[i] >= thr;
-        const unsigned long long bal = __ballot(keepit);
+    for (int i0 = 0; i0 < n; i0 += 2 * nt) {
+        const int ia = i0 + threadIdx.x, ib = ia + nt;
+        const float ra = ia < n ? resp[ia] : -1.f, rb = ib < n ? resp[ib] : -1.f;
+        const int pa = ia < n ? pos[ia] : 0, pb = ib < n ? pos[ib] : 0;
+        const bool ka = ia < n && (int)ra >= thr, kb = ib < n && (int)rb >= thr;
+        const unsigned long long ba = __ballot(ka), bb = __ballot(kb);
         int base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
+        if (lane == 0 && (ba | bb)) base = atomicAdd(&s_n, __popcll(ba) + __popcll(bb));
         base = __shfl(base, 0, 64);
-        if (keepit) candA_pos[d.cand_off + base + __popcll(bal & ((1ull << lane) - 1ull))] = pos[i];
+        if (ka) dst[base + __popcll(ba & ((1ull << lane) - 1ull))] = pa;
+        if (kb) dst[base + __popcll(ba) + __popcll(bb & ((1ull << lane) - 1ull))] = pb;
     }
     __syncthreads();
     if (threadIdx.x == 0) cnt[CNT_A + lvl] = s_n;
@@ -375,19 +485,38 @@ __device__ __forceinline__ unsigned f2key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Harris response of one candidate by one wave: lane = one of the 7x7 pixels.  Integer sums (the order of the additions
+// does not matter); the float tail is evaluated by every lane alike, lane 0's copy is the one stored.
+__device__ __forceinline__ float orb_harris_at(const uint8_t* __restrict__ lvl_img, int w, int pos, int lane)
+{
+    const int dy = lane / 7 - 3, dx = lane % 7 - 3;
+    int a = 0, b = 0, cc = 0;
+    if (lane < 49) {
+        const uint8_t* p = lvl_img + pos + dy * w + dx;
+        const int Ix = (p[1] - p[-1]) * 2 + (p[-w + 1] - p[-w - 1]) + (p[w + 1] - p[w - 1]);
+        const int Iy = (p[w] - p[-w]) * 2 + (p[w - 1] - p[-w - 1]) + (p[w + 1] - p[-w + 1]);
+        a = Ix * Ix; b = Iy * Iy; cc = Ix * Iy;
+    }
+    a = wave_sum_i32(a); b = wave_sum_i32(b); cc = wave_sum_i32(cc);
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale4 = scale * scale * scale * scale;
+    const float fa = (float)a, fb = (float)b, fc = (float)cc;
+    const float t1 = fa * fb, t2 = fc * fc, sm = fa + fb;
+    const float t4 = (0.04f * sm) * sm;
+    return ((t1 - t2) - t4) * scale4;
+}
+
 // retainBest(quota) by Harris response (radix select of the quota-th largest, ties kept), then
-// sort the survivors by position and stage them per level
-__device__ __forceinline__ void orb_harris_select(const LevelsDev& L, const int32_t* candA_pos,
-                                                  const float* candA_resp, int32_t* fin_pos,
-                                                  float* fin_resp, int32_t* tmp_pos,
-                                                  float* tmp_resp, int32_t* cnt, int* hist,
+// sort the survivors by position and stage them per level.  pos / resp: the level's candidate list (n entries), tp / tr:
+// scratch for the survivors -- global arrays, or LDS ones (scratch_in_lds: the rank pass then reads tp itself).
+__device__ __forceinline__ void orb_harris_select(const LevelsDev& L, const int32_t* pos, const float* resp, int n,
+                                                  int32_t* fin_pos, float* fin_resp, int32_t* tp, float* tr, bool scratch_in_lds,
+                                                  int32_t* cnt, int* hist, int* s_tp, int rank_cap,
                                                   unsigned& s_prefix, unsigned& s_mask, int& s_remaining, int& s_nf)
 {
     const int lvl = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const LevelDev d = L.l[lvl];
-    const int n = cnt[CNT_A + lvl], keep = d.quota;
-    const int32_t* pos = candA_pos + d.cand_off;
-    const float* resp = candA_resp + d.cand_off;
+    const int keep = d.quota;
     unsigned thr_key = 0;
     if (keep <= 0) thr_key = 0xFFFFFFFFu;  // keep nothing (n_points == 0 clears)
     else if (n > keep) {
@@ -417,8 +546,6 @@ __device__ __forceinline__ void orb_harris_select(const LevelsDev& L, const int3
     }
     if (tid == 0) s_nf = 0;
     __syncthreads();
-    int32_t* tp = tmp_pos + d.cand_off;
-    float* tr = tmp_resp + d.cand_off;
     for (int i = tid; i < n; i += nt)
         if (keep > 0 && f2key(resp[i]) >= thr_key) {
             int slot = atomicAdd(&s_nf, 1);
@@ -429,15 +556,15 @@ __device__ __forceinline__ void orb_harris_select(const LevelsDev& L, const int3
     const int nf = s_nf;
     // canonical order: ascending position (rank by counting; positions are unique).  Every thread reads every position:
     // from LDS when they fit
-    extern __shared__ int s_tp[];
-    const bool in_lds = nf <= ORB_RANK_LDS;
-    if (in_lds)
+    const bool in_lds = scratch_in_lds || nf <= rank_cap;
+    const int* const rk = scratch_in_lds ? tp : s_tp;
+    if (in_lds && !scratch_in_lds)
         for (int i = tid; i < nf; i += nt) s_tp[i] = tp[i];
     __syncthreads();
     for (int i = tid; i < nf; i += nt) {
         const int pi = tp[i];
         int rank = 0;
-        if (in_lds) for (int j = 0; j < nf; j++) rank += s_tp[j] < pi;
+        if (in_lds) for (int j = 0; j < nf; j++) rank += rk[j] < pi;
         else for (int j = 0; j < nf; j++) rank += tp[j] < pi;
         fin_pos[d.cand_off + rank] = pi;
         fin_resp[d.cand_off + rank] = tr[i];
@@ -445,17 +572,17 @@ __device__ __forceinline__ void orb_harris_select(const LevelsDev& L, const int3
     if (tid == 0) cnt[CNT_FIN + lvl] = nf;
 }
 
-// The selection in three launches: one block per pyramid level keeps retainBest(2*quota) by FAST score; the Harris
-// responses of the survivors are one WAVE per candidate across the whole device (lane = one of the 7x7 pixels; at
-// 8000 features there are ~16000 of them and one block per level spent 0.5 ms on this step alone); one block per level
+// The selection in three launches (nfeatures > 2000): one block per pyramid level keeps retainBest(2*quota) by FAST score;
+// the Harris responses of the survivors are one WAVE per candidate across the whole device (lane = one of the 7x7 pixels;
+// at 8000 features there are ~16000 of them and one block per level spent 0.5 ms on this step alone); one block per level
 // keeps retainBest(quota) by Harris and writes the canonical order.
 // (fin_* alias cand_*: the final lists replace the NMS lists, which are dead by then -- no __restrict__ there)
 __global__ void __launch_bounds__(1024) k_orb_select_fast(const LevelsDev L, const int32_t* __restrict__ cand_pos, const float* __restrict__ cand_resp,
                                                           int32_t* __restrict__ candA_pos, int32_t* __restrict__ cnt)
 {
     __shared__ int s_hist[256];
-    __shared__ int s_thr, s_n;
-    orb_fast_select(L, cand_pos, cand_resp, candA_pos, cnt, s_hist, s_thr, s_n);
+    __shared__ int s_thr, s_n, s_inlds;
+    orb_fast_select(L, cand_pos, cand_resp, candA_pos, cnt, s_hist, s_thr, s_n, nullptr, 0, s_inlds);
 }
 
 __global__ void __launch_bounds__(256) k_orb_harris(const LevelsDev L, const uint8_t* __restrict__ pimg, const int32_t* __restrict__ candA_pos,
@@ -466,27 +593,9 @@ __global__ void __launch_bounds__(256) k_orb_harris(const LevelsDev L, const uin
     const int nA = cnt[CNT_A + lvl];
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwv = gridDim.x * (blockDim.x >> 6);
-    const int dy = lane / 7 - 3, dx = lane % 7 - 3;
-    const int w = d.w;
-    // integer sums: the order of the additions does not matter; the float tail is evaluated once by lane 0
     for (int i = wv; i < nA; i += nwv) {
-        const int pos = candA_pos[d.cand_off + i];
-        int a = 0, b = 0, cc = 0;
-        if (lane < 49) {
-            const uint8_t* p = pimg + d.off + pos + dy * w + dx;
-            const int Ix = (p[1] - p[-1]) * 2 + (p[-w + 1] - p[-w - 1]) + (p[w + 1] - p[w - 1]);
-            const int Iy = (p[w] - p[-w]) * 2 + (p[w - 1] - p[-w - 1]) + (p[w + 1] - p[-w + 1]);
-            a = Ix * Ix; b = Iy * Iy; cc = Ix * Iy;
-        }
-        a = wave_sum_i32(a); b = wave_sum_i32(b); cc = wave_sum_i32(cc);
-        if (lane == 0) {
-            const float scale = 1.f / ((1 << 2) * 7 * 255.f);
-            const float scale4 = scale * scale * scale * scale;
-            const float fa = (float)a, fb = (float)b, fc = (float)cc;
-            const float t1 = fa * fb, t2 = fc * fc, sm = fa + fb;
-            const float t4 = (0.04f * sm) * sm;
-            candA_resp[d.cand_off + i] = ((t1 - t2) - t4) * scale4;
-        }
+        const float r = orb_harris_at(pimg + d.off, d.w, candA_pos[d.cand_off + i], lane);
+        if (lane == 0) candA_resp[d.cand_off + i] = r;
     }
 }
 
@@ -496,7 +605,49 @@ __global__ void __launch_bounds__(1024) k_orb_select_harris(const LevelsDev L, c
     __shared__ int s_hist[256];
     __shared__ int s_remaining, s_nf;
     __shared__ unsigned s_prefix, s_mask;
-    orb_harris_select(L, candA_pos, candA_resp, fin_pos, fin_resp, tmp_pos, tmp_resp, cnt, s_hist, s_prefix, s_mask, s_remaining, s_nf);
+    extern __shared__ int s_tp[];
+    const LevelDev d = L.l[blockIdx.x];
+    orb_harris_select(L, candA_pos + d.cand_off, candA_resp + d.cand_off, cnt[CNT_A + blockIdx.x], fin_pos, fin_resp, tmp_pos + d.cand_off,
+                      tmp_resp + d.cand_off, false, cnt, s_hist, s_tp, ORB_RANK_LDS, s_prefix, s_mask, s_remaining, s_nf);
+}
+
+// The same selection as ONE launch (nfeatures <= 2000: the odometer's 500): a block per level runs the three steps back to
+// back and keeps the lists between them in LDS -- the FAST survivors (2 x quota + score ties), their Harris responses (a wave
+// per candidate, 16 waves), the Harris survivors -- so nothing but the NMS list is read from and nothing but the final list
+// written to HBM.  As three launches each step was a chain of dependent global round trips by eight lonely blocks
+// (35 + 7 + 42 us at config 2).  A level whose survivors do not fit the LDS lists (ORB_SEL_CAP: a flood of score ties) falls
+// back to the global scratch arrays, inside the same launch.
+#define ORB_SEL_CAP 2048
+__global__ void __launch_bounds__(1024) k_orb_select(const LevelsDev L, const uint8_t* __restrict__ pimg, const int32_t* cand_pos, const float* cand_resp,
+                                                     int32_t* candA_pos, float* candA_resp, int32_t* fin_pos, float* fin_resp,
+                                                     int32_t* tmp_pos, float* tmp_resp, int32_t* cnt)
+{
+    __shared__ int s_hist[256];
+    __shared__ int s_thr, s_n, s_inlds, s_remaining, s_nf;
+    __shared__ unsigned s_prefix, s_mask;
+    __shared__ int32_t s_posA[ORB_SEL_CAP], s_posB[ORB_SEL_CAP];
+    __shared__ float s_respA[ORB_SEL_CAP], s_respB[ORB_SEL_CAP];
+    const int lvl = blockIdx.x;
+    const LevelDev d = L.l[lvl];
+    orb_fast_select(L, cand_pos, cand_resp, candA_pos, cnt, s_hist, s_thr, s_n, s_posA, ORB_SEL_CAP, s_inlds);
+    __syncthreads();
+    const bool in_lds = s_inlds != 0;
+    const int nA = s_n;
+    const int32_t* const posA = in_lds ? s_posA : candA_pos + d.cand_off;
+    float* const respA = in_lds ? s_respA : candA_resp + d.cand_off;
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+        for (int i = wv; i < nA; i += 2 * nwv) {                     // two candidates per wave in flight
+            const int j = i + nwv;
+            const int p0 = posA[i], p1 = j < nA ? posA[j] : p0;
+            const float r0 = orb_harris_at(pimg + d.off, d.w, p0, lane);
+            const float r1 = orb_harris_at(pimg + d.off, d.w, p1, lane);
+            if (lane == 0) { respA[i] = r0; if (j < nA) respA[j] = r1; }
+        }
+    }
+    __syncthreads();
+    orb_harris_select(L, posA, respA, nA, fin_pos, fin_resp, in_lds ? s_posB : tmp_pos + d.cand_off, in_lds ? s_respB : tmp_resp + d.cand_off,
+                      in_lds, cnt, s_hist, s_posB, ORB_SEL_CAP, s_prefix, s_mask, s_remaining, s_nf);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -672,20 +823,38 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
     const LevelsDev dL = *Lh;
     const int with_mask = mask_mode != 0;
     StageTimer t(ctx, VO_T_ORB);
-    hipLaunchKernelGGL(k_orb_level0, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_img, img_stride, w, h, mask_mode,
-                       d_disp16, disp_stride, min_d16, max_d16, d_mask, mask_stride, ctx->orbws->pyr_img, ctx->orbws->pyr_mask, ctx->orbws->counters);
-    for (int l = 1; l < NL; l++)
-        hipLaunchKernelGGL(k_orb_resize, dim3(div_up(Lh->l[l].w, 256), Lh->l[l].h), dim3(256), 0, ctx->stream, dL, l, ctx->rs_ofs,
-                           ctx->rs_coef, ctx->orbws->pyr_img, ctx->orbws->pyr_mask, with_mask);
+    {
+        PyrArgs pa;
+        pa.img = d_img; pa.disp16 = d_disp16; pa.mask = d_mask;
+        pa.img_stride = img_stride; pa.disp_stride = disp_stride; pa.mask_stride = mask_stride; pa.mask_mode = mask_mode;
+        pa.min_d16 = min_d16; pa.max_d16 = max_d16; pa.nbx = ctx->pyr_nbx; pa.nby = ctx->pyr_nby;
+        pa.bufA = ctx->pyr_buf[0]; pa.bufB = ctx->pyr_buf[1]; pa.tab = ctx->pyr_tab;
+        const size_t lds = (size_t)(with_mask ? 2 : 1) * (pa.bufA + pa.bufB) + (size_t)pa.tab * 16;
+        if (lds > 150 * 1024) return vo_fail(ctx, VO_E_CAP, "pyramid cones of %dx%d need %zu bytes of LDS", w, h, lds);
+        auto kp = with_mask ? k_orb_pyramid<true> : k_orb_pyramid<false>;
+        static unsigned long long attr_set[2] = { 0, 0 };     // per instantiation and device: allow more than 64 KB of dynamic LDS
+        if (!((attr_set[with_mask] >> (ctx->device & 63)) & 1ull)) {
+            VO_HIP(ctx, hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[with_mask] |= 1ull << (ctx->device & 63);
+        }
+        hipLaunchKernelGGL(kp, dim3(pa.nbx, pa.nby), dim3(256), lds, ctx->stream, dL, pa, ctx->pyr_rects, ctx->rs_ofs, ctx->rs_coef,
+                           ctx->orbws->pyr_img, ctx->orbws->pyr_mask, ctx->orbws->counters);
+    }
     hipLaunchKernelGGL(k_orb_fast_nms, dim3(div_up(w - 2 * EDGE, 64), div_up(h - 2 * EDGE, 16), NL), dim3(256), 0, ctx->stream, dL,
                        ctx->orbws->pyr_img, ctx->orbws->pyr_mask, with_mask, ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->counters);
     // after the select, cand_* hold the per-level final lists; candB_* are scratch
-    hipLaunchKernelGGL(k_orb_select_fast, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->candA_pos,
-                       ctx->orbws->counters);
-    hipLaunchKernelGGL(k_orb_harris, dim3(nfeatures > 2000 ? 256 : 32, NL), dim3(256), 0, ctx->stream, dL, ctx->orbws->pyr_img, ctx->orbws->candA_pos,
-                       ctx->orbws->candA_resp, ctx->orbws->counters);
-    hipLaunchKernelGGL(k_orb_select_harris, dim3(NL), dim3(1024), (size_t)ORB_RANK_LDS * 4, ctx->stream, dL, ctx->orbws->candA_pos, ctx->orbws->candA_resp,
-                       ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->candB_pos, ctx->orbws->candB_resp, ctx->orbws->counters);
+    if (nfeatures <= 2000) {
+        hipLaunchKernelGGL(k_orb_select, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orbws->pyr_img, ctx->orbws->cand_pos, ctx->orbws->cand_resp,
+                           ctx->orbws->candA_pos, ctx->orbws->candA_resp, ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->candB_pos,
+                           ctx->orbws->candB_resp, ctx->orbws->counters);
+    } else {
+        hipLaunchKernelGGL(k_orb_select_fast, dim3(NL), dim3(1024), 0, ctx->stream, dL, ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->candA_pos,
+                           ctx->orbws->counters);
+        hipLaunchKernelGGL(k_orb_harris, dim3(256, NL), dim3(256), 0, ctx->stream, dL, ctx->orbws->pyr_img, ctx->orbws->candA_pos,
+                           ctx->orbws->candA_resp, ctx->orbws->counters);
+        hipLaunchKernelGGL(k_orb_select_harris, dim3(NL), dim3(1024), (size_t)ORB_RANK_LDS * 4, ctx->stream, dL, ctx->orbws->candA_pos, ctx->orbws->candA_resp,
+                           ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->candB_pos, ctx->orbws->candB_resp, ctx->orbws->counters);
+    }
     hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->orbws->pyr_img, ctx->orbws->cand_pos,
                        ctx->orbws->cand_resp, ctx->orbws->counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, fs->kp_angle,
                        fs->desc);

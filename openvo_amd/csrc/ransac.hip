@@ -524,8 +524,7 @@ extern "C" int vo_mono_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
     if (rc) return rc;
     // both slots are read on this alternate's stream until p.done: whoever refills one of them waits for it first
     for (FrameSlot* f : { &a, &b }) {
-        if (f->readers[0] == p.done || f->readers[1] == p.done) continue;
-        f->readers[f->readers[0] ? 1 : 0] = p.done;
+        slot_add_reader(*f, p.done);
     }
     p.busy = true;
     ctx->mono_next = (k + 1) % vo_ctx::N_MONO_ALT;

@@ -30,6 +30,7 @@
 //   k_ccl_*        filterSpeckles (run-based union-find labelling)
 #include "vo_internal.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -56,6 +57,8 @@ __device__ __forceinline__ uint32_t pk_shr2(uint32_t a)       // both halves >> 
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) >> (u16x2){2, 2});
 }
 __device__ __forceinline__ uint32_t pk_rep(int v) { return (uint32_t)(v & 0xFFFF) * 0x00010001u; }
+// both halves = v + (the halves of add): one v_mad_u32_u24 when v < 2^16 and no half overflows (v a 15-bit cost, add = P2 twice)
+__device__ __forceinline__ uint32_t pk_rep_add(uint32_t v, uint32_t add) { return __umul24(v, 0x00010001u) + add; }
 
 #define DPP(old, src, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, 0xf, 0xf, false))
 #define ROW_SHL1 0x101
@@ -105,16 +108,19 @@ __device__ __forceinline__ void chan_bounds(const uint8_t* img, int W, int H, in
 
 __global__ void k_sgbm_planes(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
                               int ft, uint32_t* __restrict__ PL, uint32_t* __restrict__ PR, int* __restrict__ d2key,
-                              int* __restrict__ sw_ctl, int sw_ctl_words)
+                              int* __restrict__ sw_ctl, int sw_ctl_words, uint32_t* __restrict__ c_dummy, int dummy_words, uint32_t P2_2)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    // one row of cells holding P2 (= cost 0) right behind the used part of the cost volume: what the diagonal sweep reads for a
+    // pixel outside the image (such a pixel carries the border state exactly when its cost is zero)
+    if (y == 1 && blockIdx.x == 0 && (int)threadIdx.x < dummy_words) c_dummy[threadIdx.x] = P2_2;
     // the diagonal sweeps' work-item tickets, "a wait gave up" words and timelines of this run start at zero (k_sgbm_fin of
     // the previous run in this workspace has already reported its word to the slot it filled)
     if (y == 0 && blockIdx.x == 0)
         for (int i = threadIdx.x; i < sw_ctl_words; i += blockDim.x) sw_ctl[i] = 0;
     if (x >= W) return;
     size_t i = (size_t)y * W + x, plane = (size_t)W * H;
-    d2key[i] = D2_EMPTY;   // the disp2 candidates of this run start empty (saves a fill launch before the WTA)
+    if (d2key) d2key[i] = D2_EMPTY;   // uniquenessRatio >= 100 only (k_sgbm_wta keeps disp2 in HBM): its candidates start empty
     for (int c = 0; c < 2; c++) {
         int v, lo, hi;
         chan_bounds(L, W, H, x, y, c, ft, v, lo, hi);
@@ -892,6 +898,49 @@ __device__ __forceinline__ void wta_core(const LV<NP>& S, const SgbmGeom& g, int
     row_viol = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;
 }
 
+// The diagonal sweep's form of the same test.  The uniqueness rule "no d outside best-1 .. best+1 with S(d) * (100 - ur) <
+// minS * 100" is S(d) < T with T = ceil(minS * 100 / (100 - ur)) (non-negative integers), i.e. it fails exactly when MORE
+// costs lie below T than the (up to three) excluded ones do.  So this half only COUNTS the costs below T -- four saturating
+// subtractions, four clamps to {0, 1}, a packed sum and one 16-lane row sum -- and returns T; the caller knows minS and, one
+// row later, the winner's two neighbour costs (they come back from LDS for the sub-pixel fit anyway) and compares the count
+// with the number of excluded costs below T.  No per-element exclusion masks (they were ~45 instructions per pixel row).
+template <int NP, bool PAD>
+__device__ __forceinline__ void wta_count(const LV<NP>& S, const SgbmGeom& g, int lane, int& minS, int& best, int& cnt, int& Tout)
+{
+    const int l16 = lane & 15, d0 = l16 * 2 * NP;
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const int d = d0 + 2 * k;
+        if (!PAD || d < g.D) {
+            const uint32_t k0 = ((S.r[k] & 0xFFFFu) << 8) | (uint32_t)d;
+            const uint32_t k1 = ((S.r[k] >> 16) << 8) | (uint32_t)(d + 1);
+            key = min(key, min(k0, k1));
+        }
+    }
+    key = row_min_u32(key);
+    minS = (int)(key >> 8);
+    best = (int)(key & 255u);
+    // exact ceil(minS*100 / (100 - ur)) by a multiply-high with the reciprocal the host prepared (a < 2^22, 100 - ur <= 100)
+    const int T = min((int)__umulhi((unsigned)(minS * 100) + g.urAdd, g.urM), 32768);   // S <= 32767: a larger T changes nothing
+    const uint32_t T2 = pk_rep(T);
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        typedef uint16_t u16x2v __attribute__((ext_vector_type(2)));
+        const u16x2v below = __builtin_elementwise_min(__builtin_bit_cast(u16x2v, pk_sub_sat_u(T2, S.r[k])), (u16x2v){1, 1});   // 1 where S < T
+        c = pk_add(c, __builtin_bit_cast(uint32_t, below));
+    }
+    uint32_t n = (c & 0xFFFFu) + (c >> 16);
+    n += DPP(0u, n, ROW_ROR(8));
+    n += DPP(0u, n, ROW_ROR(4));
+    n += DPP(0u, n, ROW_ROR(2));
+    n += DPP(0u, n, ROW_ROR(1));
+    // (padded disparities hold the saturated sum 32767: they count only when T is 32768, and there are Dp - D of them)
+    cnt = (int)n - ((PAD && T > 32767) ? g.Dp - g.D : 0);
+    Tout = T;
+}
+
 // sub-pixel disparity (x16) of a winner from its two neighbours' costs; C's truncating division
 __device__ __forceinline__ int wta_subpixel(int best, int minS, int sm, int sp)
 {
@@ -930,7 +979,7 @@ __device__ __forceinline__ void wta_pixel(const LV<NP>& S, const SgbmGeom& g, in
     __builtin_amdgcn_wave_barrier();
 }
 
-// Second half of the fused sweep's WTA, one thread per pixel: the sweep leaves a two-word record
+// Second half of the fused sweep's WTA as a pass of its own (images too wide for k_sgbm_post_rows' LDS rows), one thread per pixel: the sweep leaves a two-word record
 // (aux0 = minS << 8 | best or -1 when the uniqueness test failed, aux1 = S[best-1] << 16 | S[best+1]);
 // this pass turns it into the sub-pixel disp1 and the disp2 candidates (atomicMin).
 // It also reports the run's health: when a wait inside one of its sweeps gave up (word 1 of a control block), the run's
@@ -1039,6 +1088,133 @@ __global__ void k_lr_median3(const int16_t* __restrict__ disp1, const int* __res
     cswap(p3, p6); cswap(p1, p4); cswap(p2, p5); cswap(p4, p7);
     cswap(p4, p2); cswap(p6, p4); cswap(p4, p2);
     dst[(size_t)y * W + x] = (int16_t)p4;
+}
+
+// ---- the diagonal sweep's records -> final disparity rows, in ONE launch (was: k_sgbm_fin, k_lr_median3, k_ccl_rows) ----------
+// Everything between the winner records and the labelled runs of filterSpeckles is local to a few image rows: the disp2
+// candidates of a row come from that row's pixels only (computeDisparitySGBM fills disp2 per row), the left-right check reads
+// its own row, medianBlur(3) reads rows y - 1 .. y + 1, and the run labelling is per row.  A block therefore takes RB rows:
+// it turns the records of rows y0 - 1 .. y0 + RB into sub-pixel disp1 and the disp2 keys (atomicMin in LDS instead of HBM),
+// applies the left-right check in place, writes the 3x3 medians of its RB rows to the disparity image and labels their runs
+// (one wave per row, wave-level prefix maximum instead of the block-wide scan).  The two halo rows are recomputed by the
+// neighbouring blocks (25 % at RB = 8); disp1 / disp2 never exist in HBM.  Also reports the run's health (see k_sgbm_planes).
+__global__ void __launch_bounds__(512) k_sgbm_post_rows(const int* __restrict__ aux0, const int* __restrict__ aux1, SgbmGeom g, int RB,
+                                                       int16_t* __restrict__ dst, int do_ccl, int maxDiff,
+                                                       int* __restrict__ L, int* __restrict__ runlen, int* __restrict__ size,
+                                                       const int* __restrict__ ctlA, const int* __restrict__ ctlB, int* sweep_word, int gen,
+                                                       int* __restrict__ sweep_errs)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_post[];
+    const int W = g.W, H = g.H, R = RB + 2;
+    int* const d2 = s_post;                                   // [R][W] disp2 keys; later [RB][W] int16 medians
+    int16_t* const d1 = (int16_t*)(s_post + (size_t)R * W);   // [R][W] disp1, then the left-right-checked values
+    const int y0 = blockIdx.x * RB, tid = threadIdx.x, nt = blockDim.x;
+    if (blockIdx.x == 0 && tid == 0 && (ctlA[1] | ctlB[1])) {
+        __hip_atomic_store(sweep_word, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        atomicAdd(sweep_errs, 1);
+    }
+    // LDS row r holds image row y0 - 1 + r (rows outside the image are never read: the median clamps its row indices)
+    for (int i = tid; i < R * W; i += nt) { d2[i] = D2_EMPTY; d1[i] = (int16_t)g.invalid16; }
+    __syncthreads();
+    for (int r = 0; r < R; r++) {
+        const int y = y0 - 1 + r;
+        if (y < 0 || y >= H) continue;                        // (block-uniform)
+        for (int x1 = tid; x1 < g.W1; x1 += nt) {
+            const int ximg = x1 + g.minX1;
+            const size_t o = (size_t)y * W + ximg;
+            const int a = aux0[o];
+            int out = g.invalid16;
+            if (a >= 0) {
+                const int minS = a >> 8, best = a & 255;
+                int dd = best * 16;
+                if (best > 0 && best < g.D - 1) {
+                    const uint32_t n = (uint32_t)aux1[o];
+                    dd = wta_subpixel(best, minS, (int)(n >> 16), (int)(n & 0xFFFFu));
+                }
+                out = dd + g.minD * 16;
+                // disp2: lowest cost wins, ties go to the pixel OpenCV scans first (largest x)
+                atomicMin(&d2[r * W + ximg - best - g.minD], (minS << 16) | (0xFFFF - ximg));
+            }
+            d1[r * W + ximg] = (int16_t)out;
+        }
+    }
+    __syncthreads();
+    // left-right check, in place (a pixel reads its own disp1 and two disp2 entries of its row)
+    for (int r = 0; r < R; r++) {
+        const int y = y0 - 1 + r;
+        if (y < 0 || y >= H) continue;
+        for (int x = g.minX1 + tid; x < g.minX1 + g.W1; x += nt) {
+            int v = d1[r * W + x];
+            if (v != g.invalid16) {
+                auto disp2 = [&](int xx) -> int {
+                    const int k = d2[r * W + xx];
+                    return k == D2_EMPTY ? g.invalid16 : (0xFFFF - (k & 0xFFFF)) - xx;  // ximg - x2 = d + minD
+                };
+                const int _d = v >> 4, d_ = (v + 15) >> 4;
+                const int _x = x - _d, x_ = x - d_;
+                if (0 <= _x && _x < W && 0 <= x_ && x_ < W) {
+                    const int a = disp2(_x), b = disp2(x_);
+                    if (a >= g.minD && abs(a - _d) > g.d12 && b >= g.minD && abs(b - d_) > g.d12) d1[r * W + x] = (int16_t)g.invalid16;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 3x3 median of the checked values (border rows / columns replicated); a copy stays in LDS for the run labelling
+    int16_t* const med = (int16_t*)d2;                        // (the disp2 keys are dead since the barrier above)
+    int p[9];
+    for (int i = tid; i < RB * W; i += nt) {
+        const int rr = i / W, x = i - rr * W, y = y0 + rr;
+        if (y >= H) break;
+        const int ra = (max(y - 1, 0) - (y0 - 1)) * W, rb = (rr + 1) * W, rc = (min(y + 1, H - 1) - (y0 - 1)) * W;
+        const int xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+        p[0] = d1[ra + xl]; p[1] = d1[ra + x]; p[2] = d1[ra + xr];
+        p[3] = d1[rb + xl]; p[4] = d1[rb + x]; p[5] = d1[rb + xr];
+        p[6] = d1[rc + xl]; p[7] = d1[rc + x]; p[8] = d1[rc + xr];
+        cswap(p[1], p[2]); cswap(p[4], p[5]); cswap(p[7], p[8]); cswap(p[0], p[1]);
+        cswap(p[3], p[4]); cswap(p[6], p[7]); cswap(p[1], p[2]); cswap(p[4], p[5]);
+        cswap(p[7], p[8]); cswap(p[0], p[3]); cswap(p[5], p[8]); cswap(p[4], p[7]);
+        cswap(p[3], p[6]); cswap(p[1], p[4]); cswap(p[2], p[5]); cswap(p[4], p[7]);
+        cswap(p[4], p[2]); cswap(p[6], p[4]); cswap(p[4], p[2]);
+        dst[(size_t)y * W + x] = (int16_t)p[4];
+        med[i] = (int16_t)p[4];
+    }
+    if (!do_ccl) return;
+    __syncthreads();
+    // filterSpeckles, first step: label[i] = index of the head of i's horizontal run (or -1), runlen[head], size[head] = 0 --
+    // one wave per row: every lane scans a chunk of consecutive pixels, the last run start before a chunk comes from an
+    // inclusive prefix maximum over the lanes
+    const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6, newVal = g.invalid16;
+    const int per = (W + 63) / 64;
+    for (int rr = wv; rr < RB; rr += nwv) {
+        const int y = y0 + rr;
+        if (y >= H) break;
+        const int16_t* const row = med + rr * W;
+        const int xa = lane * per, xb = min(xa + per, W);
+        int last = -1;
+        for (int x = xa; x < xb; x++) {
+            const int v = row[x];
+            if (v != newVal && (x == 0 || row[x - 1] == newVal || abs(v - row[x - 1]) > maxDiff)) last = x;
+        }
+        int run = last;                                        // inclusive prefix maximum over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(run, o, 64);
+            if (lane >= o) run = max(run, t);
+        }
+        int cur = __shfl_up(run, 1, 64);
+        if (lane == 0) cur = -1;
+        for (int x = xa; x < xb; x++) {
+            const int v = row[x];
+            const size_t i = (size_t)y * W + x;
+            if (v == newVal) { L[i] = -1; continue; }
+            const bool start = x == 0 || row[x - 1] == newVal || abs(v - row[x - 1]) > maxDiff;
+            if (start) { cur = x; size[i] = 0; }
+            L[i] = y * W + cur;
+            const bool end = x == W - 1 || row[x + 1] == newVal || abs(v - row[x + 1]) > maxDiff;
+            if (end) runlen[(size_t)y * W + cur] = x - cur + 1;
+        }
+    }
 }
 
 // filterSpeckles as connected-component labelling.  Edges join 4-neighbours that are both
@@ -1235,12 +1411,14 @@ static int launch_diag_k(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int
         VO_HIP(ctx, hipMemsetAsync(ctx->ws->sw_bnd, 0, need, ctx->stream));
     }
     DiagJob& j = jobs.j[0];
-    j.C = ctx->ws->C; j.in1 = in1; j.sout = sout; j.bnd = ctx->ws->sw_bnd; j.aux0 = ctx->ws->ccl_label; j.aux1 = ctx->ws->ccl_runlen;
+    j.C = ctx->ws->C; j.in1 = in1; j.sout = sout; j.bnd = ctx->ws->sw_bnd; j.aux0 = ctx->ws->rec; j.aux1 = ctx->ws->rec + (size_t)ctx->max_w * ctx->max_h + 64;
     j.tag = ++ctx->ws->sw_tag;
     if (j.tag == 0) j.tag = ++ctx->ws->sw_tag;
-    j.sink = ctx->max_w * ctx->max_h;          // every pixel array is allocated with 256 spare bytes
+    j.sink = ctx->max_w * ctx->max_h;          // 64 spare words behind each of the two record arrays
     j.dbg = ctx->tune_diag_dbg;
     j.spin_limit = ctx->tune_spin_limit;
+    j.vol_bytes = (uint32_t)(((size_t)g.W1 * g.H + 1) * g.Dp * 2);            // one volume + the dummy row behind C
+    j.rec_bytes = (uint32_t)(((size_t)ctx->max_w * ctx->max_h + 64) * 4);
     if (ctx->fault_sweep > 0 && --ctx->fault_sweep == 0) {   // (only the test-hooks build ever sets it: this launch's strips export
         j.dbg |= 2;                                          //  nothing, so every import misses and gives up after a few polls)
         j.spin_limit = 64;
@@ -1284,7 +1462,7 @@ static int launch_diag(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int16
 //     k_sgbm_paths, per-pixel winner search over all of them (k_sgbm_wta)
 // Layout of S (fused): [0] = L_W + L_E, [1] = MODE_HH: [0] + the three bottom-up directions, [2] = checkpoints of step 1.
 template <int NP>
-static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size_t vol, int* sweep_word, int gen)
+static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size_t vol)
 {
     const bool pad = g.D != g.Dp;
     const bool hh = plan.n_dirs == 8;
@@ -1324,9 +1502,6 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
         {
             StageTimer t(ctx, VO_T_SGBM_WTA);
             if (!(ctx->tune_diag_dbg & 16) && (rc = launch_diag<NP, false, true>(ctx, g, hh ? Srev : Swe, nullptr, hh ? ctlB : ctlA))) return rc;
-            hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ws->ccl_label, ctx->ws->ccl_runlen, g, ctx->ws->disp_tmp, ctx->ws->ccl_size,
-                               ctlA, ctlB, sweep_word, gen, ctx->d_sweep_errs);
-            VO_CHECK_LAUNCH(ctx);
         }
         ctx->last_paths = 3;
         ctx->last_schedule = (g.W1 % 8 == 0 && g.W1 >= 16) ? VO_SCHED_DIAG : VO_SCHED_DIAG_RAGGED;
@@ -1355,6 +1530,9 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
 }
 
 static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h);
+// rows per block of k_sgbm_post_rows: (RB + 2) rows of disp1 (2 bytes per pixel) and disp2 keys (4 bytes) must fit in LDS
+static uint32_t pk_rep_host(int v) { return (uint32_t)(v & 0xFFFF) * 0x00010001u; }
+static int post_rows_per_block(int w) { return std::min(8, (int)(150 * 1024 / ((size_t)w * 6)) - 2); }
 
 // The SGBM workspaces (planes, C, S volumes, CCL arrays) are shared by the main and the look-ahead
 // stream: a run on one stream must not start before the previous run -- possibly on the other
@@ -1408,7 +1586,8 @@ static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h)
         StageTimer t(ctx, VO_T_SGBM_COST);
         const int dbg = ctx->tune_diag_dbg;          // development only (VO_DIAG_DEBUG): 4 / 8 / 16 / 32 skip the cost / W+E / diagonal / post stage
         hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
-                           ctx->ws->planesL, ctx->ws->planesR, ctx->ws->ccl_size, ctx->ws->sw_ctl, ctx->sw_ctl_words);
+                           ctx->ws->planesL, ctx->ws->planesR, (g.ur >= 100 || post_rows_per_block(w) < 1) ? ctx->ws->ccl_size : nullptr, ctx->ws->sw_ctl, ctx->sw_ctl_words,
+                           (uint32_t*)(ctx->ws->C + vol), g.Dp / 2, pk_rep_host(g.P2));
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
         const int TY = ctx->tune_sweep_ty;
         const int nw = bx / 64;
@@ -1432,22 +1611,45 @@ static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h)
     }
     int rc;
     switch (g.Dp / 32) {
-        case 1: rc = launch_agg<1>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
-        case 2: rc = launch_agg<2>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
-        case 3: rc = launch_agg<3>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
-        case 4: rc = launch_agg<4>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
-        case 5: rc = launch_agg<5>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
-        case 6: rc = launch_agg<6>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
-        case 7: rc = launch_agg<7>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
-        default: rc = launch_agg<8>(ctx, g, plan, vol, f.sweep_word, f.disp_gen); break;
+        case 1: rc = launch_agg<1>(ctx, g, plan, vol); break;
+        case 2: rc = launch_agg<2>(ctx, g, plan, vol); break;
+        case 3: rc = launch_agg<3>(ctx, g, plan, vol); break;
+        case 4: rc = launch_agg<4>(ctx, g, plan, vol); break;
+        case 5: rc = launch_agg<5>(ctx, g, plan, vol); break;
+        case 6: rc = launch_agg<6>(ctx, g, plan, vol); break;
+        case 7: rc = launch_agg<7>(ctx, g, plan, vol); break;
+        default: rc = launch_agg<8>(ctx, g, plan, vol); break;
     }
     if (rc) return rc;
     if (!(ctx->tune_diag_dbg & 32)) {
         StageTimer t(ctx, VO_T_SGBM_POST);
-        hipLaunchKernelGGL(k_lr_median3, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, ctx->ws->disp_tmp, ctx->ws->ccl_size, g, d_disp);
-        if (e.speckleWindow > 0) {
-            const int newVal = g.invalid16, maxDiff = 16 * e.speckleRange;
-            hipLaunchKernelGGL(k_ccl_rows, dim3(h), dim3(256), 0, ctx->stream, d_disp, w, newVal, maxDiff, ctx->ws->ccl_label, ctx->ws->ccl_runlen, ctx->ws->ccl_size);
+        const int newVal = g.invalid16, maxDiff = 16 * e.speckleRange;
+        const bool speckle = e.speckleWindow > 0;
+        // rows per block of the fused kernel: (RB + 2) rows of disp1 (2 bytes) and disp2 keys (4 bytes) must fit in LDS
+        const int rb = post_rows_per_block(w);
+        if (ctx->last_schedule != VO_SCHED_UNFUSED && rb >= 1) {
+            // records of the diagonal sweep -> sub-pixel disp1 + disp2 -> left-right check -> medianBlur(3) -> labelled runs: one launch
+            static unsigned long long attr_set = 0;
+            if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
+                VO_HIP(ctx, hipFuncSetAttribute((const void*)k_sgbm_post_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set |= 1ull << (ctx->device & 63);
+            }
+            const int* const ctlA = ctx->ws->sw_ctl;
+            const int* const ctlB = ctx->ws->sw_ctl + ctx->sw_ctl_words / 2;
+            hipLaunchKernelGGL(k_sgbm_post_rows, dim3(div_up(h, rb)), dim3(512), (size_t)(rb + 2) * w * 6, ctx->stream, ctx->ws->rec,
+                               ctx->ws->rec + (size_t)ctx->max_w * ctx->max_h + 64, g, rb, d_disp, speckle ? 1 : 0, maxDiff, ctx->ws->ccl_label,
+                               ctx->ws->ccl_runlen, ctx->ws->ccl_size, ctlA, ctlB, f.sweep_word, f.disp_gen, ctx->d_sweep_errs);
+        } else {
+            if (ctx->last_schedule != VO_SCHED_UNFUSED) {
+                // (an image too wide for the fused kernel's LDS rows: the same steps as separate passes over HBM)
+                hipLaunchKernelGGL(k_sgbm_fin, dim3(div_up(g.W1, 256), g.H), dim3(256), 0, ctx->stream, ctx->ws->rec, ctx->ws->rec + (size_t)ctx->max_w * ctx->max_h + 64,
+                                   g, ctx->ws->disp_tmp, ctx->ws->ccl_size, ctx->ws->sw_ctl, ctx->ws->sw_ctl + ctx->sw_ctl_words / 2, f.sweep_word, f.disp_gen, ctx->d_sweep_errs);
+            }
+            hipLaunchKernelGGL(k_lr_median3, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, ctx->ws->disp_tmp, ctx->ws->ccl_size, g, d_disp);
+            if (speckle)
+                hipLaunchKernelGGL(k_ccl_rows, dim3(h), dim3(256), 0, ctx->stream, d_disp, w, newVal, maxDiff, ctx->ws->ccl_label, ctx->ws->ccl_runlen, ctx->ws->ccl_size);
+        }
+        if (speckle) {
             hipLaunchKernelGGL(k_ccl_vmerge, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_runlen);
             hipLaunchKernelGGL(k_ccl_sizes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_runlen, ctx->ws->ccl_size);
             hipLaunchKernelGGL(k_ccl_apply, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_disp, n, newVal, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_size);

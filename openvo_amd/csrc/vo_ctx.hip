@@ -163,12 +163,12 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     VO_HIP(ctx, hipMemset(ctx->ws->sw_ctl, 0, ctx->sw_ctl_words * sizeof(int)));
     DALLOC(ctx->ws->disp_tmp, npx); DALLOC(ctx->dump, 4096);
     DALLOC(ctx->ws->ccl_label, npx); DALLOC(ctx->ws->ccl_size, npx); DALLOC(ctx->ws->ccl_runlen, npx);
+    DALLOC(ctx->ws->rec, 2 * (npx + 64));
     // ORB: 8-level pyramid is < 3.2x the base image
     ctx->pyr_bytes = npx * 4;
     DALLOC(ctx->rs_ofs, (size_t)(max_w + max_h) * 2 * VO_ORB_LEVELS);
     DALLOC(ctx->rs_coef, (size_t)(max_w + max_h) * 4 * VO_ORB_LEVELS);
-    DALLOC(ctx->rs_meta, 64 * VO_ORB_LEVELS);
-    VO_HIP(ctx, hipMalloc(&ctx->d_levels, 4096));
+    DALLOC(ctx->pyr_rects, 4096);
     // FAST candidates after NMS are never 8-adjacent: at most ceil(w/2)*ceil(h/2) per level
     ctx->cand_cap = (int)((size_t)((max_w + 1) / 2) * ((max_h + 1) / 2));
     // (summed over the 8 levels: < 3.2x that)
@@ -205,6 +205,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
         const int fit = (int)(budget / per_engine);
         if (ctx->n_engines > fit) ctx->n_engines = fit < 2 ? 2 : fit;
     }
+    if (const char* e9 = getenv("VO_POSE_STREAMS")) { int v = atoi(e9); if (v >= 1 && v <= vo_ctx::N_POSE_STREAMS) ctx->n_pose_streams = v; }
     if (const char* e27 = getenv("VO_DIAG_WGS")) ctx->tune_diag_wgs = atoi(e27);
     if (const char* e26 = getenv("VO_DIAG_DEBUG")) ctx->tune_diag_dbg = atoi(e26);
     if (const char* e27 = getenv("VO_STAGGER")) ctx->tune_stagger = atoi(e27);
@@ -236,7 +237,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
         if (f.ready) (void)hipEventDestroy(f.ready);
     }
     void* ps[] = { ctx->stage_in, ctx->map1[0], ctx->map1[1], ctx->map2[0], ctx->map2[1], ctx->ws->planesL, ctx->ws->planesR,
-                   ctx->ws->C, ctx->ws->S, ctx->ws->sw_bnd, ctx->ws->sw_ctl, ctx->ws->disp_tmp, ctx->dump, ctx->ws->ccl_runlen, ctx->ws->ccl_label, ctx->ws->ccl_size, ctx->rs_ofs, ctx->rs_coef, ctx->rs_meta, ctx->d_levels, ctx->mw->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
+                   ctx->ws->C, ctx->ws->S, ctx->ws->sw_bnd, ctx->ws->sw_ctl, ctx->ws->disp_tmp, ctx->dump, ctx->ws->ccl_runlen, ctx->ws->ccl_label, ctx->ws->ccl_size, ctx->ws->rec, ctx->rs_ofs, ctx->rs_coef, ctx->pyr_rects, ctx->mw->m_count, ctx->host_mask_dev, ctx->mq, ctx->mt,
                    ctx->mw->m_idx, ctx->mw->m_dist, ctx->mw->pts_a, ctx->mw->pts_b, ctx->mw->st_a, ctx->mw->st_b, ctx->mw->xy_a, ctx->mw->xy_b,
                    ctx->mw->mq_idx, ctx->mw->mt_idx, ctx->red, ctx->mw->clique_ws, ctx->img3_ws, ctx->mw->ransac_ws, ctx->d_sweep_errs };
     for (void* p : ps) if (p) (void)hipFree(p);
@@ -250,7 +251,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     if (ctx->ws->done) (void)hipEventDestroy(ctx->ws->done);
     for (int k = 0; k < vo_ctx::MAX_ENGINES; k++) {
         vo_ctx::SgbmWs& a = ctx->ws_alt[k];
-        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.sw_bnd, a.sw_ctl, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, ctx->la_stage[k] };
+        void* pa[] = { a.planesL, a.planesR, a.C, a.S, a.sw_bnd, a.sw_ctl, a.disp_tmp, a.ccl_runlen, a.ccl_label, a.ccl_size, a.rec, ctx->la_stage[k] };
         for (void* q : pa) if (q) (void)hipFree(q);
         if (a.done) (void)hipEventDestroy(a.done);
         orb_ws_free(a.orb);
@@ -552,9 +553,9 @@ static int engine_prepare(vo_ctx* ctx, int engine)
     const size_t npx = (size_t)ctx->max_w * ctx->max_h;
     const int vols = 3;                          // L_W + L_E, MODE_HH's reverse-pass sum, checkpoints (ensure_S grows it if ever needed)
     void** ps[] = { (void**)&a.planesL, (void**)&a.planesR, (void**)&a.C, (void**)&a.S, (void**)&a.sw_ctl, (void**)&a.disp_tmp,
-                    (void**)&a.ccl_runlen, (void**)&a.ccl_label, (void**)&a.ccl_size };
+                    (void**)&a.ccl_runlen, (void**)&a.ccl_label, (void**)&a.ccl_size, (void**)&a.rec };
     const size_t sz[] = { npx * 2 * 4, npx * 6 * 4, ctx->vol_cells * 2, ctx->vol_cells * 2 * vols, ctx->sw_ctl_words * sizeof(int), npx * 2,
-                          npx * 4, npx * 4, npx * 4 };
+                          npx * 4, npx * 4, npx * 4, (npx + 64) * 8 };
     hipError_t e = hipSuccess;
     for (size_t k = 0; k < sizeof(ps) / sizeof(ps[0]) && e == hipSuccess; k++) e = hipMalloc(ps[k], sz[k] + 256);
     if (e == hipSuccess) e = hipMemset(a.sw_ctl, 0, ctx->sw_ctl_words * sizeof(int));
@@ -599,6 +600,20 @@ int slot_before_overwrite(vo_ctx* ctx, FrameSlot& f)
     for (hipEvent_t& r : f.readers)
         if (r) { VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, r, 0)); r = nullptr; }
     return VO_OK;
+}
+
+// Registers the completion event of an asynchronous step that reads the slot.  The slot keeps two entries: an entry is free
+// when it is empty or its event has completed; with both still open (a step begun on a slot while two earlier readers of
+// it are unfinished) the older one is waited for here, on the host, rather than dropped from the set a refill orders
+// itself behind.
+void slot_add_reader(FrameSlot& f, hipEvent_t done)
+{
+    for (hipEvent_t r : f.readers) if (r == done) return;
+    for (hipEvent_t& r : f.readers)
+        if (!r || hipEventQuery(r) == hipSuccess) { r = done; return; }
+    (void)hipEventSynchronize(f.readers[0]);
+    f.readers[0] = f.readers[1];
+    f.readers[1] = done;
 }
 
 // common tail of the look-ahead entry points: ingest (device or pinned-host source) + SGBM (+ ORB) of one
@@ -752,7 +767,9 @@ extern "C" int vo_prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* left, cons
 static int host_stage_alloc(vo_ctx* ctx)
 {
     // first use of the staging path: every buffer at once (a pinned allocation takes about a millisecond -- not something to
-    // pay inside a stream, buffer by buffer)
+    // pay inside a stream, buffer by buffer).  Under the staging lock: vo_host_stage_pair may run on a helper thread of the
+    // caller while the driving thread calls vo_host_stage_begin.
+    std::lock_guard<std::mutex> lk(ctx->stage_mu);
     for (vo_ctx::HostStage& q : ctx->host_stage) {
         if (q.pinned) continue;
         if (hipHostMalloc((void**)&q.pinned, ctx->stage_bytes * 2, hipHostMallocDefault) != hipSuccess) return VO_E_HIP;

@@ -94,6 +94,7 @@ struct vo_ctx {
         uint32_t *planesL = nullptr, *planesR = nullptr;
         int16_t *C = nullptr, *S = nullptr, *disp_tmp = nullptr;
         int32_t *ccl_runlen = nullptr, *ccl_label = nullptr, *ccl_size = nullptr;
+        int32_t* rec = nullptr;          // the diagonal sweep's winner records: two arrays of max_w * max_h + 64 words
         int S_vols = 0;
         uint64_t* sw_bnd = nullptr;
         size_t sw_bnd_bytes = 0;
@@ -164,8 +165,12 @@ struct vo_ctx {
     size_t pyr_bytes = 0;
     int32_t* rs_ofs = nullptr;     // resize tables (all levels): x then y offsets
     uint16_t* rs_coef = nullptr;
-    int32_t* rs_meta = nullptr;    // per level: table offsets + min/max
-    void* d_levels = nullptr;      // device copy of level descriptors
+    // k_orb_pyramid: the pyramid is cut into pyr_nbx x pyr_nby cones (one workgroup each); pyr_rects = per level the column
+    // interval every cone column needs (own part + what the next level's interval reads), then the row intervals:
+    // [l][bx][2] (inclusive lo, hi) for x, followed by [l][by][2] for y.  pyr_buf[2] = bytes of the largest even- / odd-level
+    // rectangle (the kernel's two ping-pong LDS buffers per image kind).
+    int32_t* pyr_rects = nullptr;
+    int pyr_nbx = 0, pyr_nby = 0, pyr_buf[2] = {0, 0}, pyr_tab = 0;
     char rs_meta_host[1024];       // host copy of the level descriptors (LevelsDev)
     int orb_quota_nfeatures = -1;  // nfeatures the device quotas were uploaded for
     int cand_cap = 0;
@@ -195,6 +200,7 @@ struct vo_ctx {
     // sweep stalls behind a descheduled neighbour (measured: 23 streams -> 200-1000 pairs/s).  Steps that share a stream run
     // back to back without the host in between; their scratch and records are separate.
     static const int N_POSE_STREAMS = 3;
+    int n_pose_streams = N_POSE_STREAMS;     // VO_POSE_STREAMS (1..3): fewer when the GPU's hardware queues are shared with other processes
     hipStream_t pose_streams[N_POSE_STREAMS] = {};
     struct PoseAlt {
         hipStream_t stream = nullptr;
@@ -300,6 +306,8 @@ int xfer_flush(vo_ctx* ctx);
 int slot_wait(vo_ctx* ctx, FrameSlot& f);
 // the stream the context currently works on is about to overwrite the slot: order it behind work that still writes or reads it
 int slot_before_overwrite(vo_ctx* ctx, FrameSlot& f);
+// `done` marks the end of an asynchronous step that reads the slot: whoever overwrites the slot waits for it first
+void slot_add_reader(FrameSlot& f, hipEvent_t done);
 int orb_slot_enqueue(vo_ctx* ctx, FrameSlot& f, int nfeatures, int mask_mode, int min_disp16, int max_disp16);
 void pose_alt_free(vo_ctx* ctx);
 void mono_alt_free(vo_ctx* ctx);

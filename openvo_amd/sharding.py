@@ -111,7 +111,7 @@ class Group:
     """world processes of one node.  Control plane: a star of TCP sockets around rank 0.  Data plane for the
     pose gather: RCCL when `attach_rccl` succeeded, the sockets otherwise."""
 
-    def __init__(self, rank, world, master_addr="127.0.0.1", key=None, timeout=300.0):
+    def __init__(self, rank, world, master_addr=None, key=None, timeout=300.0):
         self.rank, self.world = int(rank), int(world)
         self._peers, self._sock, self._mgpu, self._lib, self._late = [], None, None, None, None
         self.transport = "socket"
@@ -119,9 +119,10 @@ class Group:
             return
         key = key or rendezvous_key()
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "vo355_rdzv_%s.json" % key)
-        # the ranks of one node meet on the loopback interface unless told otherwise (VO_RDZV_BIND): nothing outside the
-        # node has any business connecting here, and a launcher's MASTER_ADDR may be a name that does not resolve
-        master_addr = os.environ.get("VO_RDZV_BIND", "127.0.0.1")
+        # the ranks of one node meet on the loopback interface unless told otherwise (the master_addr argument, else
+        # VO_RDZV_BIND): nothing outside the node has any business connecting here, and a launcher's MASTER_ADDR may be a
+        # name that does not resolve
+        master_addr = master_addr or os.environ.get("VO_RDZV_BIND", "127.0.0.1")
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -140,9 +141,14 @@ class Group:
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 conn.settimeout(timeout)
                 (r,) = struct.unpack("<I", _recv_exact(conn, 4))
-                if not (1 <= r < self.world) or r in peers:     # not one of this job's ranks (or one that is already here)
+                if not (1 <= r < self.world) or r in peers:     # not one of this job's ranks (or one that is already here):
+                    try:                                        # told so before the door closes, so that it fails at once
+                        conn.sendall(b"\x00")
+                    except OSError:
+                        pass
                     conn.close()
                     continue
+                conn.sendall(b"\x01")
                 peers[r] = conn
             srv.close()
             self._peers = [peers[r] for r in range(1, self.world)]
@@ -161,6 +167,11 @@ class Group:
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
             s.sendall(struct.pack("<I", self.rank))
+            if _recv_exact(s, 1) != b"\x01":
+                s.close()
+                raise ConnectionError("rank %d was turned away by the rank 0 listening at %s:%s (rendezvous file %s): another job's "
+                                      "rendezvous, or this rank number is already connected -- give the jobs different "
+                                      "MASTER_PORT / VO_RUN_ID values" % (self.rank, info["addr"], info["port"], path))
             self._sock = s
 
     # -- control plane (sockets)
@@ -305,8 +316,10 @@ def rendezvous_key():
     """Names the rendezvous file of one job on this node: the launcher's MASTER_ADDR:MASTER_PORT plus its run id when it
     exports one (torch.distributed.run: TORCHELASTIC_RUN_ID) -- the same for every rank of a job whatever started them
     (ranks need not share a parent process), different for two jobs on one node."""
-    raw = "%s_%s_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
-                        os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("VO_RUN_ID", "")))
+    run = os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("VO_RUN_ID", ""))
+    if not run and not os.environ.get("MASTER_PORT"):
+        run = "ppid%d" % os.getppid()      # nothing names the job: ranks forked by one parent still find each other, two such jobs do not collide
+    raw = "%s_%s_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"), run)
     return "".join(ch if ch.isalnum() or ch in "._-" else "-" for ch in raw)
 
 
@@ -329,12 +342,13 @@ def init_from_env(want_rccl=True):
     g = Group(rank, world)
     ndev = device_count()
     masked = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
-    if world > 1 and 0 < ndev < world and not masked and os.environ.get("VO_SHARE_GPU", "0") != "1":
+    if world > 1 and 0 < ndev < world and not masked and os.environ.get("VO_SHARE_GPU", "0") in ("", "0"):
         # several ranks on one GPU oversubscribe its hardware queues (12 engines each: measured 96 pairs/s instead of 1400);
-        # a launcher that gives every rank a device of its own masks them per rank.  Rehearsals opt in with VO_SHARE_GPU=1.
+        # a launcher that gives every rank a device of its own masks them per rank.  Rehearsals opt in with
+        # VO_SHARE_GPU=<ranks per GPU>, set BEFORE openvo_amd is imported: every rank then takes its share of the queues.
         g.close()
         raise RuntimeError("%d ranks but only %d visible GPU(s) and no per-rank device mask: refusing to share a GPU "
-                           "(set VO_SHARE_GPU=1 for a rehearsal with reduced engines)" % (world, ndev))
+                           "(set VO_SHARE_GPU=<ranks per GPU> in the ranks' environment for a rehearsal)" % (world, ndev))
     device = local if ndev >= world else local % max(ndev, 1)
     if want_rccl and world > 1 and ndev >= world and os.environ.get("VO_NO_RCCL", "0") != "1":
         g.attach_rccl(device)

@@ -216,6 +216,30 @@ def rodrigues(R):
     return r.reshape(3, 1)
 
 
+def stereo_rectify(K1, D1, K2, D2, img_size, R, T):
+    """cv2.stereoRectify(K1, D1, K2, D2, imageSize, R, T) with its Python defaults -> R1, R2, P1, P2, Q, roi1, roi2"""
+    K1, K2, R, T = _c(K1, np.float64), _c(K2, np.float64), _c(np.asarray(R, np.float64).reshape(3, 3), np.float64), _c(np.asarray(T, np.float64).reshape(3), np.float64)
+    d1 = _c(np.zeros(0) if D1 is None else np.asarray(D1, np.float64).ravel(), np.float64)
+    d2 = _c(np.zeros(0) if D2 is None else np.asarray(D2, np.float64).ravel(), np.float64)
+    R1, R2, P1, P2, Q = np.empty((3, 3)), np.empty((3, 3)), np.empty((3, 4)), np.empty((3, 4)), np.empty((4, 4))
+    roi1, roi2 = np.zeros(4, np.int32), np.zeros(4, np.int32)
+    lib().vo_ref_stereo_rectify(_p(K1), _p(d1), len(d1), _p(K2), _p(d2), len(d2), int(img_size[0]), int(img_size[1]), _p(R), _p(T),
+                                _p(R1), _p(R2), _p(P1), _p(P2), _p(Q), _p(roi1), _p(roi2))
+    return R1, R2, P1, P2, Q, tuple(int(v) for v in roi1), tuple(int(v) for v in roi2)
+
+
+def init_undistort_rectify_map(K, dist, R, P, img_size):
+    """cv2.initUndistortRectifyMap(K, dist, R, P, size, CV_16SC2) -> (map1 int16 HxWx2, map2 uint16 HxW)"""
+    K, R, P = _c(K, np.float64), _c(np.eye(3) if R is None else R, np.float64), _c(P, np.float64)
+    d = _c(np.zeros(0) if dist is None else np.asarray(dist, np.float64).ravel(), np.float64)
+    w, h = int(img_size[0]), int(img_size[1])
+    m1, m2 = np.empty((h, w, 2), np.int16), np.empty((h, w), np.uint16)
+    Pm = np.zeros((3, 4))
+    Pm[:, :P.shape[1]] = P[:3]
+    lib().vo_ref_init_undistort_rectify_map(_p(K), _p(d), len(d), _p(R), _p(_c(Pm, np.float64)), w, h, _p(m1), _p(m2))
+    return m1, m2
+
+
 def rigid_clique(prev, cur, thr):
     prev, cur = _c(prev, np.float32), _c(cur, np.float32)
     mask = np.zeros(len(cur), np.int64)

@@ -130,6 +130,14 @@ int vo_ref_reproj_count(const float* P12, const float* X, const float* uv, int n
 int vo_ref_ransac_pnp(const float* X, const float* uv, int n, const double* K4, int iters, float thr, uint32_t seed,
                       double* Rt_best12, uint8_t* mask, int32_t* counts, int* best_iter);
 
+/* ---- one-off rectification setup (reference stereo_camera.py:17-22): cv2.stereoRectify with its Python defaults and
+ * cv2.initUndistortRectifyMap(..., CV_16SC2); the checker of openvo_amd/calib.py (src/calib.c) ---------------------------- */
+void vo_ref_stereo_rectify(const double* K1, const double* d1, int n1, const double* K2, const double* d2, int n2, int w, int h,
+                           const double* R9, const double* T3, double* R1_9, double* R2_9, double* P1_12, double* P2_12, double* Q16,
+                           int* roi1_xywh, int* roi2_xywh);
+void vo_ref_init_undistort_rectify_map(const double* K9, const double* d, int nd, const double* R9, const double* P12, int w, int h,
+                                       int16_t* map1 /*h*w*2*/, uint16_t* map2 /*h*w*/);
+
 #ifdef __cplusplus
 }
 #endif

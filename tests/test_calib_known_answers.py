@@ -230,3 +230,43 @@ def test_vertical_rig_uses_the_other_axis():
     R1, R2, P1, P2, Q, _, _ = calib.stereo_rectify(K, None, K, None, (W, H), np.eye(3), [0.0, -0.15, 0.0])
     assert P1[0, 0] == 450.0 and P2[0, 3] == 0 and abs(P2[1, 3] + 0.15 * 450.0) < 1e-12
     assert abs(Q[3, 2] - 1 / 0.15) < 1e-12
+
+
+# ---- the product's calib.py against its checker: the C restatement in oracle/src/calib.c ----------------------------------
+def _rigs():
+    rot = _rodrigues(RIG["om"])
+    yield "rotated_distorted", np.array(RIG["K1"]), RIG["d1"], np.array(RIG["K2"]), RIG["d2"], np.array(rot), RIG["T"], (W, H)
+    yield "ideal", _K(718.856, 718.856, 640.0, 360.0), np.zeros(5), _K(718.856, 718.856, 640.0, 360.0), np.zeros(5), np.eye(3), [-0.537, 0, 0], (1280, 720)
+    yield "vertical", _K(500.0, 505.0, 322.0, 241.0), [0.05, -0.02, 0, 0, 0], _K(515.0, 512.0, 318.0, 238.0), [0.03, 0.01, 0.001, -0.001, 0],\
+        np.array(_rodrigues([0.004, 0.006, -0.011])), [0.003, -0.18, 0.002], (W, H)
+    yield "eight_coefficients", _K(610.0, 612.0, 300.0, 250.0), [-0.2, 0.05, 0.001, 0.0005, -0.004, 0.01, -0.002, 0.0003], \
+        _K(605.0, 609.0, 330.0, 236.0), [-0.18, 0.04, -0.0007, 0.0002, -0.003, 0.008, -0.001, 0.0002], \
+        np.array(_rodrigues([-0.02, 0.03, 0.01])), [0.25, -0.006, 0.004], (W, H)
+    yield "no_distortion_given", _K(400.0, 400.0, 160.0, 120.0), None, _K(400.0, 400.0, 160.0, 120.0), None, np.eye(3), [-0.12, 0, 0], (320, 240)
+
+
+def test_calib_py_equals_the_c_oracle(oracle):
+    """openvo_amd/calib.py is the product; oracle/src/calib.c restates cvStereoRectify / icvGetRectangles /
+    initUndistortRectifyMap + convertMaps independently (scalar C, pixel by pixel).  R1, R2, P1, P2, Q agree to 1e-12,
+    the valid ROIs exactly, the fixed-point maps everywhere except isolated rounding ties (<= 1 LSB, < 1e-4 of the pixels).
+    Reference call sites: stereo_camera.py:17-22."""
+    n = 0
+    for name, K1, d1, K2, d2, R, T, size in _rigs():
+        got = calib.stereo_rectify(K1, d1, K2, d2, size, R, T)
+        ref = oracle.stereo_rectify(K1, d1, K2, d2, size, R, T)
+        for g, r, what in zip(got[:5], ref[:5], ("R1", "R2", "P1", "P2", "Q")):
+            assert np.allclose(g, r, rtol=0, atol=1e-12), (name, what, np.abs(np.asarray(g) - r).max())
+        assert tuple(got[5]) == tuple(ref[5]) and tuple(got[6]) == tuple(ref[6]), (name, got[5:], ref[5:])
+        assert got[5][2] > 0 and got[5][3] > 0
+        for K, d, Rk, P in ((K1, d1, got[0], got[2]), (K2, d2, got[1], got[3])):
+            m1, m2 = calib.init_undistort_rectify_map(K, d, Rk, P, size)
+            o1, o2 = oracle.init_undistort_rectify_map(K, d, Rk, P, size)
+            assert m1.shape == o1.shape and m2.shape == o2.shape and m1.dtype == o1.dtype and m2.dtype == o2.dtype
+            # compare as Q5 fixed-point positions: (map1 << 5) + fraction
+            fu, fv = m1[..., 0].astype(np.int64) * 32 + (m2 & 31), m1[..., 1].astype(np.int64) * 32 + (m2 >> 5)
+            gu, gv = o1[..., 0].astype(np.int64) * 32 + (o2 & 31), o1[..., 1].astype(np.int64) * 32 + (o2 >> 5)
+            du, dv = np.abs(fu - gu), np.abs(fv - gv)
+            assert du.max() <= 1 and dv.max() <= 1, (name, int(du.max()), int(dv.max()))
+            assert ((du + dv) > 0).mean() < 1e-4, (name, float(((du + dv) > 0).mean()))
+            n += 1
+    assert n == 10

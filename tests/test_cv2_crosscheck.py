@@ -46,18 +46,21 @@ def pair():
 
 
 # ---- (a) the oracle against cv2, on CPU ------------------------------------------------------------------------
-def test_oracle_stereo_rectify_and_maps_equal_cv2():
-    got = calib.stereo_rectify(RIG["K1"], RIG["d1"], RIG["K2"], RIG["d2"], (640, 480), RIG["R"], RIG["T"])
+def test_oracle_stereo_rectify_and_maps_equal_cv2(oracle):
+    """cv2.stereoRectify / initUndistortRectifyMap against BOTH restatements: the checker (oracle/src/calib.c) and the
+    product's host code (openvo_amd/calib.py) -- tests/test_calib_known_answers.py holds the two against each other."""
     ref = cv2.stereoRectify(RIG["K1"], RIG["d1"], RIG["K2"], RIG["d2"], (640, 480), RIG["R"], RIG["T"])
-    for g, r, name in zip(got[:5], ref[:5], ("R1", "R2", "P1", "P2", "Q")):
-        assert np.allclose(g, r, rtol=0, atol=1e-9), name
-    assert tuple(got[5]) == tuple(ref[5]) and tuple(got[6]) == tuple(ref[6])
-    for K, d, R, P in ((RIG["K1"], RIG["d1"], ref[0], ref[2]), (RIG["K2"], RIG["d2"], ref[1], ref[3])):
-        m1, m2 = calib.init_undistort_rectify_map(K, d, R, P, (640, 480))
-        c1, c2 = cv2.initUndistortRectifyMap(K, d, R, P, (640, 480), cv2.CV_16SC2)
-        # float rounding of u*32 may flip a fixed-point LSB on isolated pixels; nothing larger
-        assert (np.abs(m1.astype(int) - c1.astype(int)).max() <= 1) and ((m1 != c1).any(-1).mean() < 1e-3)
-        assert (m2 != c2).mean() < 1e-3
+    for impl, who in ((oracle, "oracle/src/calib.c"), (calib, "openvo_amd/calib.py")):
+        got = impl.stereo_rectify(RIG["K1"], RIG["d1"], RIG["K2"], RIG["d2"], (640, 480), RIG["R"], RIG["T"])
+        for g, r, name in zip(got[:5], ref[:5], ("R1", "R2", "P1", "P2", "Q")):
+            assert np.allclose(g, r, rtol=0, atol=1e-9), (who, name)
+        assert tuple(got[5]) == tuple(ref[5]) and tuple(got[6]) == tuple(ref[6]), who
+        for K, d, R, P in ((RIG["K1"], RIG["d1"], ref[0], ref[2]), (RIG["K2"], RIG["d2"], ref[1], ref[3])):
+            m1, m2 = impl.init_undistort_rectify_map(K, d, R, P, (640, 480))
+            c1, c2 = cv2.initUndistortRectifyMap(K, d, R, P, (640, 480), cv2.CV_16SC2)
+            # float rounding of u*32 may flip a fixed-point LSB on isolated pixels; nothing larger
+            assert (np.abs(m1.astype(int) - c1.astype(int)).max() <= 1) and ((m1 != c1).any(-1).mean() < 1e-3), who
+            assert (m2 != c2).mean() < 1e-3, who
 
 
 def test_oracle_image_stages_equal_cv2(oracle, pair):

@@ -335,3 +335,30 @@ def test_more_ranks_than_gpus_is_refused_without_a_mask(monkeypatch):
     monkeypatch.setenv("VO_SHARE_GPU", "1")
     g, dev = sharding.init_from_env(want_rccl=False)
     assert dev == 0 and g.world == 2
+
+
+def test_bench_orchestration_with_eight_socket_ranks(tmp_path):
+    """bench.py --gpus 8 as the driver launches it (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), with the
+    GPU work replaced by stand-ins (tests/bench_standin.py): eight ranks render their frames at the same time (the synthetic
+    generator's library is built once behind a lock), meet on the socket transport, take the max of every window over the
+    ranks, gather their poses, and rank 0 prints ONE JSON line with the contract's fields, the window samples and the host
+    cores available per rank."""
+    import json
+    world = 8
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               PYTHONPATH=ROOT, VO_NO_RCCL="1", VO_RUN_ID="standin-%d" % os.getpid())
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_standin.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2",
+           "--repeats", "2", "--cpu-pairs", "0", "--no-post", "--no-other"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and all(not o[0].strip() for o in outs[1:])          # rank 0 prints the one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["unit"] == "frame-pairs/s"
+    assert len(d["window_values"]) == 2 and d["ms_per_step"] == pytest.approx(float(np.median(d["window_ms"])) / 4, rel=1e-3)
+    assert d["value"] == pytest.approx(4 * world / (d["ms_per_step"] * 4 / 1e3), rel=1e-3)      # whole-job pairs over the max-over-ranks time
+    assert d["frames"] == world * 8 and d["accepted_frames"] == world * 8 and d["shard_boundaries_inexact"] == []
+    assert d["cores_per_rank"] == pytest.approx(len(os.sched_getaffinity(0)) / world, abs=0.01)
+    assert d["rccl"]["transport"] == "socket" and d["rccl"]["world"] == world
