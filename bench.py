@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=5,
                     help="cold-start windows of --steps pairs each, back to back on consecutive frames; `value` is their median "
                          "(capped so that at most 600 frames are rendered)")
+    ap.add_argument("--mix-stages", action="store_true",
+                    help="diagnostic: one more steady pass with HIP events around EVERY stage on its own stream -> `stage_ms_per_pair_in_mix` "
+                         "(a stage's latency beside the other pairs' kernels; the events themselves cost some throughput)")
     ap.add_argument("--steady", type=int, default=480,
                     help="pairs of the untimed-for-`value` steady-state pass reported as `steady_state` (0 = skip)")
     args = ap.parse_args()
@@ -201,6 +204,24 @@ def bench_stereo(args, group, device, workload, K, W, light):
         cam.lookahead_stop = None
         sodo.reset_lookahead()
         sweep_err |= ctx.sgbm_sweep_status()
+    tmix, mix_rate = None, None
+    if S_steady and args.mix_stages:
+        modo = StereoOdometer(cam, **ODO_KW)
+        for i in range(W):
+            modo.update(staged[i], None)
+        modo.reset_lookahead()
+        ctx.enable_timing(True)
+        ctx.timings(reset=True)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(W, W + S_steady):
+            modo.update(staged[i], None)
+        ctx.synchronize()
+        mix_rate = S_steady / (time.perf_counter() - t0)
+        tmix = ctx.timings(reset=True)
+        ctx.enable_timing(False)
+        modo.reset_lookahead()
+        modo = None
     gc.enable()
     schedule = {1: "diag", 2: "diag_ragged", 3: "unfused"}.get(ctx.sgbm_last_schedule(), "?")
 
@@ -351,6 +372,9 @@ def bench_stereo(args, group, device, workload, K, W, light):
             out["rccl"] = group.describe()        # what the communicator itself reports (ranks, this rank), not a string we made up
         if tb is not None:
             out["stage_ms_per_pair_alone"] = {k: round(v[0] / max(nb + 1, 1), 4) for k, v in tb.items()}
+        if tmix is not None:
+            out["stage_ms_per_pair_in_mix"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in tmix.items()}
+            out["stage_mix_pass_pairs_per_s"] = round(mix_rate, 1)
         if from_host_rate is not None:
             out["from_host_pairs_per_s"] = round(from_host_rate, 2)    # PCIe-inclusive; never `value`
             out["from_host_window"] = "96 pairs after 8 untimed ones (host numpy arrays through StereoOdometer.run)"

@@ -108,8 +108,8 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h)
     int pyr_nbx, pyr_nby, pyr_buf[2] = { 0, 0 }, pyr_tab = 0;
     {
         const LevelDev& top = L.l[NL - 1];
-        pyr_nbx = std::max(1, std::min({ div_up(w, 88), top.w / 8, 40 }));
-        pyr_nby = std::max(1, std::min({ div_up(h, 80), top.h / 8, 40 }));
+        pyr_nbx = std::max(1, std::min({ div_up(w, 64), top.w / 8, 48 }));
+        pyr_nby = std::max(1, std::min({ div_up(h, 48), top.h / 8, 48 }));
         auto intervals = [&](int nb, bool xaxis, std::vector<int32_t>& out) {     // out[l][b][2]
             out.assign((size_t)NL * nb * 2, 0);
             for (int b = 0; b < nb; b++) {
@@ -144,7 +144,7 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h)
         }
         rects = rx;
         rects.insert(rects.end(), ry.begin(), ry.end());
-        if (rects.size() > 4096) return vo_fail(ctx, VO_E_CAP, "pyramid cone table exceeds its capacity");
+        if (rects.size() > 4096 / 4 * 4) return vo_fail(ctx, VO_E_CAP, "pyramid cone table exceeds its capacity");
     }
     if ((size_t)cand_off > (size_t)ctx->cand_cap * 4) return vo_fail(ctx, VO_E_CAP, "candidate capacity exceeded");
     if (ofs.size() > (size_t)(ctx->max_w + ctx->max_h) * 2 * NL) return vo_fail(ctx, VO_E_CAP, "resize tables exceed capacity");
@@ -203,81 +203,148 @@ __global__ void __launch_bounds__(256) k_orb_pyramid(const LevelsDev L, const Py
                                                      const int32_t* __restrict__ ofs, const uint16_t* __restrict__ coef,
                                                      uint8_t* __restrict__ pimg, uint8_t* __restrict__ pmask, int32_t* __restrict__ cnt)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_pyr[];
-    // [img even | img odd | mask even | mask odd | x taps: o0, o1 (u16) c0, c1 (u16) | y taps]
-    uint8_t* const bimg[2] = { s_pyr, s_pyr + A.bufA };
-    uint8_t* const bmsk[2] = { s_pyr + A.bufA + A.bufB, s_pyr + 2 * A.bufA + A.bufB };
-    uint16_t* const tx = (uint16_t*)(s_pyr + (MASK ? 2 : 1) * (A.bufA + A.bufB));     // [tab][4]
-    uint16_t* const ty = tx + 4 * A.tab;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_pyr_generic[];
+    // (explicit LDS address space: a pointer picked from an array by a run-time index is a generic pointer to the compiler, and
+    // every access through it a flat_load / flat_store)
+    typedef __attribute__((address_space(3))) uint8_t lds8;
+    typedef __attribute__((address_space(3))) uint16_t lds16;
+    typedef __attribute__((address_space(3))) int lds32;
+    lds8* const s_pyr = (lds8*)s_pyr_generic;
+    // [img even | img odd | mask even | mask odd | taps of levels 1 .. 7: per level x then y entries {o0, o1, c0, c1} (u16)]
+    const unsigned o_img[2] = { 0u, (unsigned)A.bufA }, o_msk[2] = { (unsigned)(A.bufA + A.bufB), (unsigned)(2 * A.bufA + A.bufB) };
+    lds16* const taps = (lds16*)(s_pyr + (MASK ? 2 : 1) * (A.bufA + A.bufB));           // [NL - 1][2 * tab][4]
+    lds32* const s_rect = (lds32*)(taps + (size_t)(NL - 1) * 2 * A.tab * 4);            // [NL][4] (no static LDS: the dynamic region may be all 160 KB)
+#define RECT(l, k) s_rect[(l) * 4 + (k)]
     const int bx = blockIdx.x, by = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (bx == 0 && by == 0 && threadIdx.x < CNT_HIST) cnt[threadIdx.x] = 0;           // the run's counters start here
-    const int32_t* const rxs = rects;
-    const int32_t* const rys = rects + NL * A.nbx * 2;
-    int px0 = 0, py0 = 0, pnw = 0;                                                    // rectangle of the level below (origin, pitch)
-    for (int l = 0; l < NL; l++) {
-        const LevelDev d = L.l[l];
-        const int x0 = rxs[(l * A.nbx + bx) * 2], x1 = rxs[(l * A.nbx + bx) * 2 + 1];
-        const int y0 = rys[(l * A.nby + by) * 2], y1 = rys[(l * A.nby + by) * 2 + 1];
+    // every level's rectangle, then every level's taps: two batches of independent global loads instead of one dependent
+    // round trip per level
+    if (threadIdx.x < NL * 4) {
+        const int l = threadIdx.x >> 2, k = threadIdx.x & 3;
+        RECT(l, k) = k < 2 ? rects[(l * A.nbx + bx) * 2 + k] : rects[NL * A.nbx * 2 + (l * A.nby + by) * 2 + (k - 2)];
+    }
+    __syncthreads();
+    // (all of a thread's table reads first, then the LDS writes: one global round trip for the lot instead of one per entry)
+    {
+        constexpr int TB = 8;
+        const int ntap = (NL - 1) * 2 * A.tab;
+        for (int ib = threadIdx.x; ib < ntap; ib += TB * blockDim.x) {
+            int o0[TB], c0[TB], c1[TB], org[TB], kind[TB];          // kind: 0 = skip, 1 = clamped tap, 2 = table tap
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int i = ib + u * blockDim.x;
+                kind[u] = 0; o0[u] = 0; c0[u] = 256; c1[u] = 0; org[u] = 0;
+                if (i >= ntap) continue;
+                const int l = 1 + i / (2 * A.tab), j = i - (l - 1) * 2 * A.tab;
+                const bool isx = j < A.tab;
+                const int e = isx ? j : j - A.tab;
+                const int lo = RECT(l, isx ? 0 : 2), hi = RECT(l, isx ? 1 : 3);
+                if (e > hi - lo) continue;
+                const LevelDev d = L.l[l];
+                const LevelDev p = L.l[l - 1];
+                const int v = lo + e;
+                const int mn = isx ? d.min_x : d.min_y, mx = isx ? d.max_x : d.max_y, t0 = isx ? d.xt : d.yt;
+                const int ssz = isx ? p.w : p.h;
+                org[u] = RECT(l - 1, isx ? 0 : 2);
+                if (v < mn) { kind[u] = 1; o0[u] = 0; }
+                else if (v >= mx) { kind[u] = 1; o0[u] = ssz - 1; }
+                else { kind[u] = 2; o0[u] = ofs[t0 + v]; c0[u] = coef[2 * (size_t)(t0 + v)]; c1[u] = coef[2 * (size_t)(t0 + v) + 1]; }
+            }
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                if (!kind[u]) continue;
+                lds16* t = taps + (size_t)(ib + u * blockDim.x) * 4;
+                t[0] = (uint16_t)(o0[u] - org[u]); t[1] = (uint16_t)(o0[u] + (kind[u] == 2 ? 1 : 0) - org[u]); t[2] = (uint16_t)c0[u]; t[3] = (uint16_t)c1[u];
+            }
+        }
+    }
+    // level 0: the cropped left image and its mask (feature_mask, or the caller's)
+    {
+        const LevelDev d = L.l[0];
+        const int x0 = RECT(0, 0), x1 = RECT(0, 1), y0 = RECT(0, 2), y1 = RECT(0, 3);
         const int nw = x1 - x0 + 1, nh = y1 - y0 + 1;
+        lds8* const b0i = s_pyr + o_img[0];
+        lds8* const b0m = s_pyr + o_msk[0];
         const int ox0 = (int)((long long)bx * d.w / A.nbx), ox1 = (int)((long long)(bx + 1) * d.w / A.nbx);     // owned part [ox0, ox1)
         const int oy0 = (int)((long long)by * d.h / A.nby), oy1 = (int)((long long)(by + 1) * d.h / A.nby);
-        uint8_t* const di = bimg[l & 1];
-        uint8_t* const dm = bmsk[l & 1];
-        if (l == 0) {
-            for (int yy = wv; yy < nh; yy += 4) {
-                const int y = y0 + yy;
-                for (int xx = lane; xx < nw; xx += 64) {
-                    const int x = x0 + xx;
-                    const uint8_t v = A.img[(size_t)y * A.img_stride + x];
-                    di[yy * nw + xx] = v;
-                    const bool own = x >= ox0 && x < ox1 && y >= oy0 && y < oy1;
-                    if (own) pimg[(size_t)y * d.w + x] = v;
+        // (twelve rows of a column per lane in flight: a load per iteration would be one dependent global round trip per row)
+        constexpr int RB0 = 12;
+        for (int xx = lane; xx < nw; xx += 64) {
+            const int x = x0 + xx;
+            const bool ownx = x >= ox0 && x < ox1;
+            for (int yb = wv; yb < nh; yb += 4 * RB0) {
+                uint8_t v[RB0], m[RB0];
+#pragma unroll
+                for (int u = 0; u < RB0; u++) {
+                    const int yy = min(yb + 4 * u, nh - 1), y = y0 + yy;
+                    v[u] = A.img[(size_t)y * A.img_stride + x];
                     if (MASK) {
-                        uint8_t m;
                         if (A.mask_mode == 1) {
                             const int dd = A.disp16[(size_t)y * A.disp_stride + x];
-                            m = (dd >= A.min_d16 && dd <= A.max_d16) ? 255 : 0;
+                            m[u] = (dd >= A.min_d16 && dd <= A.max_d16) ? 255 : 0;
                         } else
-                            m = A.mask[(size_t)y * A.mask_stride + x];
-                        dm[yy * nw + xx] = m;
-                        if (own) pmask[(size_t)y * d.w + x] = m;
+                            m[u] = A.mask[(size_t)y * A.mask_stride + x];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < RB0; u++) {
+                    const int yy = yb + 4 * u, y = y0 + yy;
+                    if (yy >= nh) break;
+                    const bool own = ownx && y >= oy0 && y < oy1;
+                    b0i[yy * nw + xx] = v[u];
+                    if (own) pimg[(size_t)y * d.w + x] = v[u];
+                    if (MASK) {
+                        b0m[yy * nw + xx] = m[u];
+                        if (own) pmask[(size_t)y * d.w + x] = m[u];
                     }
                 }
             }
-        } else {
-            const LevelDev p = L.l[l - 1];
-            // this level's taps, relative to the rectangle of the level below: {o0, o1, c0, c1} per column / row
-            for (int i = threadIdx.x; i < nw + nh; i += blockDim.x) {
-                const bool isx = i < nw;
-                const int v = isx ? x0 + i : y0 + (i - nw);
-                const int mn = isx ? d.min_x : d.min_y, mx = isx ? d.max_x : d.max_y, t0 = isx ? d.xt : d.yt;
-                const int ssz = isx ? p.w : p.h, org = isx ? px0 : py0;
-                int o0, o1, c0 = 256, c1 = 0;
-                if (v < mn) o0 = o1 = 0;
-                else if (v >= mx) o0 = o1 = ssz - 1;
-                else { o0 = ofs[t0 + v]; o1 = o0 + 1; c0 = coef[2 * (size_t)(t0 + v)]; c1 = coef[2 * (size_t)(t0 + v) + 1]; }
-                uint16_t* t = (isx ? tx + 4 * i : ty + 4 * (i - nw));
-                t[0] = (uint16_t)(o0 - org); t[1] = (uint16_t)(o1 - org); t[2] = (uint16_t)c0; t[3] = (uint16_t)c1;
-            }
-            __syncthreads();
-            const uint8_t* const si = bimg[(l - 1) & 1];
-            const uint8_t* const sm = bmsk[(l - 1) & 1];
-            for (int yy = wv; yy < nh; yy += 4) {
-                const int y = y0 + yy;
-                const unsigned r0 = ty[4 * yy] * (unsigned)pnw, r1 = ty[4 * yy + 1] * (unsigned)pnw, yc0 = ty[4 * yy + 2], yc1 = ty[4 * yy + 3];
-                for (int xx = lane; xx < nw; xx += 64) {
-                    const int x = x0 + xx;
-                    const unsigned a0 = tx[4 * xx], a1 = tx[4 * xx + 1], xc0 = tx[4 * xx + 2], xc1 = tx[4 * xx + 3];
-                    const bool own = x >= ox0 && x < ox1 && y >= oy0 && y < oy1;
+        }
+    }
+    __syncthreads();
+    for (int l = 1; l < NL; l++) {
+        const LevelDev d = L.l[l];
+        const int x0 = RECT(l, 0), x1 = RECT(l, 1), y0 = RECT(l, 2), y1 = RECT(l, 3);
+        const int nw = x1 - x0 + 1, nh = y1 - y0 + 1;
+        const int pnw = RECT(l - 1, 1) - RECT(l - 1, 0) + 1;                          // pitch of the rectangle below
+        const int ox0 = (int)((long long)bx * d.w / A.nbx), ox1 = (int)((long long)(bx + 1) * d.w / A.nbx);
+        const int oy0 = (int)((long long)by * d.h / A.nby), oy1 = (int)((long long)(by + 1) * d.h / A.nby);
+        lds8* const di = s_pyr + o_img[l & 1];
+        lds8* const dm = s_pyr + o_msk[l & 1];
+        const lds8* const si = s_pyr + o_img[(l - 1) & 1];
+        const lds8* const sm = s_pyr + o_msk[(l - 1) & 1];
+        const lds16* const tx = taps + (size_t)(l - 1) * 2 * A.tab * 4;
+        const lds16* const ty = tx + (size_t)A.tab * 4;
+        for (int xx = lane; xx < nw; xx += 64) {            // a lane keeps its column's taps in registers while it walks the rows
+            const int x = x0 + xx;
+            const unsigned a0 = tx[4 * xx], a1 = tx[4 * xx + 1], xc0 = tx[4 * xx + 2], xc1 = tx[4 * xx + 3];
+            const bool ownx = x >= ox0 && x < ox1;
+            for (int yb = wv; yb < nh; yb += 16) {          // four rows per lane in flight (LDS reads first, then the arithmetic)
+                unsigned r0[4], r1[4], yc0[4], yc1[4], ti[4][4], tm[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int yy = min(yb + 4 * u, nh - 1);
+                    r0[u] = ty[4 * yy] * (unsigned)pnw; r1[u] = ty[4 * yy + 1] * (unsigned)pnw; yc0[u] = ty[4 * yy + 2]; yc1[u] = ty[4 * yy + 3];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ti[u][0] = si[r0[u] + a0]; ti[u][1] = si[r0[u] + a1]; ti[u][2] = si[r1[u] + a0]; ti[u][3] = si[r1[u] + a1];
+                    if (MASK) { tm[u][0] = sm[r0[u] + a0]; tm[u][1] = sm[r0[u] + a1]; tm[u][2] = sm[r1[u] + a0]; tm[u][3] = sm[r1[u] + a1]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int yy = yb + 4 * u, y = y0 + yy;
+                    if (yy >= nh) break;
+                    const bool own = ownx && y >= oy0 && y < oy1;
                     {
-                        const unsigned h0 = xc0 * si[r0 + a0] + xc1 * si[r0 + a1], h1 = xc0 * si[r1 + a0] + xc1 * si[r1 + a1];
-                        const unsigned out = (h0 * yc0 + h1 * yc1 + 32768u) >> 16;
+                        const unsigned h0 = xc0 * ti[u][0] + xc1 * ti[u][1], h1 = xc0 * ti[u][2] + xc1 * ti[u][3];
+                        const unsigned out = (h0 * yc0[u] + h1 * yc1[u] + 32768u) >> 16;
                         di[yy * nw + xx] = (uint8_t)out;
                         if (own) pimg[d.off + (size_t)y * d.w + x] = (uint8_t)out;
                     }
                     if (MASK) {
-                        const unsigned h0 = xc0 * sm[r0 + a0] + xc1 * sm[r0 + a1], h1 = xc0 * sm[r1 + a0] + xc1 * sm[r1 + a1];
-                        unsigned out = (h0 * yc0 + h1 * yc1 + 32768u) >> 16;
+                        const unsigned h0 = xc0 * tm[u][0] + xc1 * tm[u][1], h1 = xc0 * tm[u][2] + xc1 * tm[u][3];
+                        unsigned out = (h0 * yc0[u] + h1 * yc1[u] + 32768u) >> 16;
                         out = out > 254u ? out : 0u;
                         dm[yy * nw + xx] = (uint8_t)out;
                         if (own) pmask[d.off + (size_t)y * d.w + x] = (uint8_t)out;
@@ -285,9 +352,9 @@ __global__ void __launch_bounds__(256) k_orb_pyramid(const LevelsDev L, const Py
                 }
             }
         }
-        px0 = x0; py0 = y0; pnw = nw;
         __syncthreads();
     }
+#undef RECT
 }
 
 // ---------------------------------------------------------------------------------------
@@ -366,11 +433,23 @@ __global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev L, const u
     __shared__ uint8_t s_sc[SH * SP];
     __shared__ int s_cnt[16];
     __shared__ int s_base;
-    const int lvl = blockIdx.z;
+    // A compact one-dimensional grid walks the tiles of all levels (level-major): a (tiles_x, tiles_y, levels) grid sized for
+    // level 0 launched 6720 workgroups at config 2 of which 60 % returned at once -- and every workgroup of a short kernel has
+    // to win a slot from the dispatcher against the other pairs' sweeps.
+    int tiles_before[NL + 1];
+    tiles_before[0] = 0;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        const int iw = L.l[l].w - 2 * EDGE, ih = L.l[l].h - 2 * EDGE;
+        tiles_before[l + 1] = tiles_before[l] + (iw > 0 && ih > 0 ? ((iw + TW - 1) / TW) * ((ih + TH - 1) / TH) : 0);
+    }
+    for (int tile = blockIdx.x; tile < tiles_before[NL]; tile += gridDim.x) {
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < NL; l++) lvl += tile >= tiles_before[l];
     const LevelDev d = L.l[lvl];
-    if (d.w <= 2 * EDGE || d.h <= 2 * EDGE) return;  // block-uniform (depends on the level only)
-    const int x0 = blockIdx.x * TW + EDGE, y0 = blockIdx.y * TH + EDGE;
-    if (x0 >= d.w - EDGE || y0 >= d.h - EDGE) return;  // block-uniform
+    const int tpr = (d.w - 2 * EDGE + TW - 1) / TW, tl = tile - tiles_before[lvl];
+    const int x0 = (tl % tpr) * TW + EDGE, y0 = (tl / tpr) * TH + EDGE;
     const int xlim = d.w - EDGE + 1, ylim = d.h - EDGE + 1;   // scores are needed up to one pixel past the interior
     const uint8_t* img = pimg + d.off;
     for (int i = threadIdx.x; i < SW * SH; i += blockDim.x) {
@@ -415,6 +494,38 @@ __global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev L, const u
             cand_resp[d.cand_off + slot] = (float)sc[r];
         }
     }
+    __syncthreads();                                 // (the next tile reuses the LDS arrays)
+    }
+}
+
+// Walks a 256-bin histogram (LDS) from bin 255 downwards until the running count reaches `need`: returns that bin and the
+// count ABOVE it.  By the first wave of the block, all 64 lanes (lane l sums bins 255 - 4 l .. 252 - 4 l, one wave-wide
+// inclusive prefix, the lane where the prefix crosses `need` resolves its four bins): ~40 instructions instead of a 256-step
+// loop of dependent LDS reads on one thread (8 us each, five of them per level in the selection).  Returns bin -1 when the
+// whole histogram holds fewer than `need` entries.
+__device__ __forceinline__ void hist_scan_desc(const int* hist, int need, int lane, int& bin, int& above)
+{
+    const int b0 = 255 - 4 * lane;
+    const int h0 = hist[b0], h1 = hist[b0 - 1], h2 = hist[b0 - 2], h3 = hist[b0 - 3];
+    const int s = (h0 + h1) + (h2 + h3);
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    const unsigned long long hit = __ballot(inc >= need);
+    bin = -1; above = 0;
+    if (hit) {
+        const int f = __ffsll((long long)hit) - 1;
+        int c = __shfl(inc - s, f, 64);
+        const int g0 = __shfl(h0, f, 64), g1 = __shfl(h1, f, 64), g2 = __shfl(h2, f, 64);
+        const int fb = 255 - 4 * f;
+        if (c + g0 >= need) { bin = fb; above = c; }
+        else if (c + g0 + g1 >= need) { bin = fb - 1; above = c + g0; }
+        else if (c + g0 + g1 + g2 >= need) { bin = fb - 2; above = c + g0 + g1; }
+        else { bin = fb - 3; above = c + g0 + g1 + g2; }
+    }
 }
 
 // retainBest(2*quota) by FAST score: keep every candidate whose score >= the n-th largest.  The survivors go to `lds_pos`
@@ -442,35 +553,48 @@ __device__ __forceinline__ void orb_fast_select(const LevelsDev& L, const int32_
             for (int k = 0; k < 4; k++) if (r[k] >= 0.f) atomicAdd(&s_hist[(int)r[k] & 255], 1);
         }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
         int thr = 0, kept = n;
         if (keep == 0) { thr = 1 << 30; kept = 0; }
         else if (n > keep) {
-            int cum = 0;
-            for (int b = 255; b >= 0; b--) {
-                cum += s_hist[b];
-                if (cum >= keep) { thr = b; break; }
-            }
-            kept = cum;
+            int bin, above;
+            hist_scan_desc(s_hist, keep, threadIdx.x, bin, above);
+            thr = max(bin, 0);
+            kept = above + s_hist[thr];
         }
-        s_thr = thr;
-        s_inlds = lds_pos != nullptr && kept <= lds_cap;
+        if (threadIdx.x == 0) {
+            s_thr = thr;
+            s_inlds = lds_pos != nullptr && kept <= lds_cap;
+        }
     }
     __syncthreads();
     const int thr = s_thr;
     int32_t* const dst = s_inlds ? lds_pos : outA + d.cand_off;
     const int lane = threadIdx.x & 63;
-    for (int i0 = 0; i0 < n; i0 += 2 * nt) {
-        const int ia = i0 + threadIdx.x, ib = ia + nt;
-        const float ra = ia < n ? resp[ia] : -1.f, rb = ib < n ? resp[ib] : -1.f;
-        const int pa = ia < n ? pos[ia] : 0, pb = ib < n ? pos[ib] : 0;
-        const bool ka = ia < n && (int)ra >= thr, kb = ib < n && (int)rb >= thr;
-        const unsigned long long ba = __ballot(ka), bb = __ballot(kb);
+    for (int i0 = 0; i0 < n; i0 += 4 * nt) {                        // four candidates per thread in flight
+        float r[4];
+        int p[4];
+        unsigned long long bal[4];
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + k * nt + threadIdx.x;
+            r[k] = i < n ? resp[i] : -1.f;
+            p[k] = i < n ? pos[i] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            bal[k] = __ballot(r[k] >= 0.f && (int)r[k] >= thr);
+            tot += __popcll(bal[k]);
+        }
         int base = 0;
-        if (lane == 0 && (ba | bb)) base = atomicAdd(&s_n, __popcll(ba) + __popcll(bb));
+        if (lane == 0 && tot) base = atomicAdd(&s_n, tot);
         base = __shfl(base, 0, 64);
-        if (ka) dst[base + __popcll(ba & ((1ull << lane) - 1ull))] = pa;
-        if (kb) dst[base + __popcll(ba) + __popcll(bb & ((1ull << lane) - 1ull))] = pb;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((bal[k] >> lane) & 1ull) dst[base + __popcll(bal[k] & ((1ull << lane) - 1ull))] = p[k];
+            base += __popcll(bal[k]);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) cnt[CNT_A + lvl] = s_n;
@@ -509,8 +633,11 @@ __device__ __forceinline__ float orb_harris_at(const uint8_t* __restrict__ lvl_i
 // retainBest(quota) by Harris response (radix select of the quota-th largest, ties kept), then
 // sort the survivors by position and stage them per level.  pos / resp: the level's candidate list (n entries), tp / tr:
 // scratch for the survivors -- global arrays, or LDS ones (scratch_in_lds: the rank pass then reads tp itself).
-__device__ __forceinline__ void orb_harris_select(const LevelsDev& L, const int32_t* pos, const float* resp, int n,
-                                                  int32_t* fin_pos, float* fin_resp, int32_t* tp, float* tr, bool scratch_in_lds,
+// (PI / PF / SI / SF: pointer types of the candidate list and of the scratch -- global, or LDS with its address space spelled
+// out: through generic pointers every access would be a flat_load / flat_store)
+template <typename PI, typename PF, typename SI, typename SF>
+__device__ __forceinline__ void orb_harris_select(const LevelsDev& L, PI pos, PF resp, int n,
+                                                  int32_t* fin_pos, float* fin_resp, SI tp, SF tr, bool scratch_in_lds,
                                                   int32_t* cnt, int* hist, int* s_tp, int rank_cap,
                                                   unsigned& s_prefix, unsigned& s_mask, int& s_remaining, int& s_nf)
 {
@@ -532,13 +659,14 @@ __device__ __forceinline__ void orb_harris_select(const LevelsDev& L, const int3
                 if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
             }
             __syncthreads();
-            if (tid == 0) {
-                int cum = 0, rem = s_remaining;
-                for (int b = 255; b >= 0; b--) {
-                    if (cum + hist[b] >= rem) { s_prefix = prefix | ((unsigned)b << shift); s_remaining = rem - cum; break; }
-                    cum += hist[b];
+            if (tid < 64) {
+                int bin, above;
+                const int rem = s_remaining;
+                hist_scan_desc(hist, rem, tid, bin, above);
+                if (tid == 0) {
+                    if (bin >= 0) { s_prefix = prefix | ((unsigned)bin << shift); s_remaining = rem - above; }
+                    s_mask = mask | (255u << shift);
                 }
-                s_mask = mask | (255u << shift);
             }
             __syncthreads();
         }
@@ -557,14 +685,14 @@ __device__ __forceinline__ void orb_harris_select(const LevelsDev& L, const int3
     // canonical order: ascending position (rank by counting; positions are unique).  Every thread reads every position:
     // from LDS when they fit
     const bool in_lds = scratch_in_lds || nf <= rank_cap;
-    const int* const rk = scratch_in_lds ? tp : s_tp;
     if (in_lds && !scratch_in_lds)
         for (int i = tid; i < nf; i += nt) s_tp[i] = tp[i];
     __syncthreads();
     for (int i = tid; i < nf; i += nt) {
         const int pi = tp[i];
         int rank = 0;
-        if (in_lds) for (int j = 0; j < nf; j++) rank += rk[j] < pi;
+        if (scratch_in_lds) for (int j = 0; j < nf; j++) rank += tp[j] < pi;
+        else if (in_lds) for (int j = 0; j < nf; j++) rank += s_tp[j] < pi;
         else for (int j = 0; j < nf; j++) rank += tp[j] < pi;
         fin_pos[d.cand_off + rank] = pi;
         fin_resp[d.cand_off + rank] = tr[i];
@@ -631,23 +759,35 @@ __global__ void __launch_bounds__(1024) k_orb_select(const LevelsDev L, const ui
     const LevelDev d = L.l[lvl];
     orb_fast_select(L, cand_pos, cand_resp, candA_pos, cnt, s_hist, s_thr, s_n, s_posA, ORB_SEL_CAP, s_inlds);
     __syncthreads();
-    const bool in_lds = s_inlds != 0;
     const int nA = s_n;
-    const int32_t* const posA = in_lds ? s_posA : candA_pos + d.cand_off;
-    float* const respA = in_lds ? s_respA : candA_resp + d.cand_off;
-    {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-        for (int i = wv; i < nA; i += 2 * nwv) {                     // two candidates per wave in flight
-            const int j = i + nwv;
-            const int p0 = posA[i], p1 = j < nA ? posA[j] : p0;
-            const float r0 = orb_harris_at(pimg + d.off, d.w, p0, lane);
-            const float r1 = orb_harris_at(pimg + d.off, d.w, p1, lane);
-            if (lane == 0) { respA[i] = r0; if (j < nA) respA[j] = r1; }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    auto harris = [&](auto posA, auto respA) {
+        for (int i = wv; i < nA; i += 4 * nwv) {                     // four candidates per wave in flight
+            int p[4];
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) p[k] = posA[min(i + k * nwv, nA - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = orb_harris_at(pimg + d.off, d.w, p[k], lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (lane == 0 && i + k * nwv < nA) respA[i + k * nwv] = r[k];
         }
+    };
+    typedef __attribute__((address_space(3))) int32_t lds_i32;
+    typedef __attribute__((address_space(3))) float lds_f32;
+    if (s_inlds) {                                                   // (block-uniform)
+        lds_i32* const pA = (lds_i32*)s_posA;
+        lds_f32* const rA = (lds_f32*)s_respA;
+        harris(pA, rA);
+        __syncthreads();
+        orb_harris_select(L, (const lds_i32*)pA, (const lds_f32*)rA, nA, fin_pos, fin_resp, (lds_i32*)s_posB, (lds_f32*)s_respB, true, cnt, s_hist,
+                          s_posB, ORB_SEL_CAP, s_prefix, s_mask, s_remaining, s_nf);
+    } else {
+        harris((const int32_t*)(candA_pos + d.cand_off), candA_resp + d.cand_off);
+        __syncthreads();
+        orb_harris_select(L, (const int32_t*)(candA_pos + d.cand_off), (const float*)(candA_resp + d.cand_off), nA, fin_pos, fin_resp,
+                          tmp_pos + d.cand_off, tmp_resp + d.cand_off, false, cnt, s_hist, s_posB, ORB_SEL_CAP, s_prefix, s_mask, s_remaining, s_nf);
     }
-    __syncthreads();
-    orb_harris_select(L, posA, respA, nA, fin_pos, fin_resp, in_lds ? s_posB : tmp_pos + d.cand_off, in_lds ? s_respB : tmp_resp + d.cand_off,
-                      in_lds, cnt, s_hist, s_posB, ORB_SEL_CAP, s_prefix, s_mask, s_remaining, s_nf);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -702,7 +842,7 @@ __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev L, const u
                                                      int32_t* __restrict__ cnt, int cap, float* __restrict__ kp_xy,
                                                      float* __restrict__ kp_size, float* __restrict__ kp_resp,
                                                      int32_t* __restrict__ kp_oct, float* __restrict__ kp_angle,
-                                                     uint8_t* __restrict__ desc)
+                                                     uint8_t* __restrict__ desc, int32_t* n_kp_host)
 {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -714,7 +854,12 @@ __global__ void __launch_bounds__(256) k_orb_describe(const LevelsDev L, const u
         if (k >= total + c) { lvl = l + 1; base = total + c; }
         total += c;
     }
-    if (k == 0 && lane == 0) cnt[CNT_TOTAL] = total;
+    if (k == 0 && lane == 0) {
+        cnt[CNT_TOTAL] = total;
+        // the keypoint count goes straight into the slot's pinned host word (a 4-byte copy command behind this kernel was one
+        // more queue entry per pair)
+        __hip_atomic_store(n_kp_host, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (k >= min(total, cap)) return;
     const LevelDev d = L.l[lvl];
     const int w = d.w, pos = fin_pos[d.cand_off + (k - base)];
@@ -829,7 +974,7 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
         pa.img_stride = img_stride; pa.disp_stride = disp_stride; pa.mask_stride = mask_stride; pa.mask_mode = mask_mode;
         pa.min_d16 = min_d16; pa.max_d16 = max_d16; pa.nbx = ctx->pyr_nbx; pa.nby = ctx->pyr_nby;
         pa.bufA = ctx->pyr_buf[0]; pa.bufB = ctx->pyr_buf[1]; pa.tab = ctx->pyr_tab;
-        const size_t lds = (size_t)(with_mask ? 2 : 1) * (pa.bufA + pa.bufB) + (size_t)pa.tab * 16;
+        const size_t lds = (size_t)(with_mask ? 2 : 1) * (pa.bufA + pa.bufB) + (size_t)(NL - 1) * 2 * pa.tab * 8 + NL * 16;
         if (lds > 150 * 1024) return vo_fail(ctx, VO_E_CAP, "pyramid cones of %dx%d need %zu bytes of LDS", w, h, lds);
         auto kp = with_mask ? k_orb_pyramid<true> : k_orb_pyramid<false>;
         static unsigned long long attr_set[2] = { 0, 0 };     // per instantiation and device: allow more than 64 KB of dynamic LDS
@@ -840,7 +985,10 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
         hipLaunchKernelGGL(kp, dim3(pa.nbx, pa.nby), dim3(256), lds, ctx->stream, dL, pa, ctx->pyr_rects, ctx->rs_ofs, ctx->rs_coef,
                            ctx->orbws->pyr_img, ctx->orbws->pyr_mask, ctx->orbws->counters);
     }
-    hipLaunchKernelGGL(k_orb_fast_nms, dim3(div_up(w - 2 * EDGE, 64), div_up(h - 2 * EDGE, 16), NL), dim3(256), 0, ctx->stream, dL,
+    int fast_tiles = 0;
+    for (int l = 0; l < NL; l++)
+        if (Lh->l[l].w > 2 * EDGE && Lh->l[l].h > 2 * EDGE) fast_tiles += div_up(Lh->l[l].w - 2 * EDGE, 64) * div_up(Lh->l[l].h - 2 * EDGE, 16);
+    hipLaunchKernelGGL(k_orb_fast_nms, dim3(std::max(1, std::min(fast_tiles, 2048))), dim3(256), 0, ctx->stream, dL,
                        ctx->orbws->pyr_img, ctx->orbws->pyr_mask, with_mask, ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->counters);
     // after the select, cand_* hold the per-level final lists; candB_* are scratch
     if (nfeatures <= 2000) {
@@ -857,9 +1005,8 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
     }
     hipLaunchKernelGGL(k_orb_describe, dim3(div_up(ctx->kp_cap, 4)), dim3(256), 0, ctx->stream, dL, ctx->orbws->pyr_img, ctx->orbws->cand_pos,
                        ctx->orbws->cand_resp, ctx->orbws->counters, ctx->kp_cap, fs->kp_xy, fs->kp_size, fs->kp_resp, fs->kp_oct, fs->kp_angle,
-                       fs->desc);
+                       fs->desc, fs->n_kp_host);
     VO_CHECK_LAUNCH(ctx);
-    VO_HIP(ctx, hipMemcpyAsync(fs->n_kp_host, ctx->orbws->counters + CNT_TOTAL, 4, hipMemcpyDeviceToHost, ctx->stream));
     return VO_OK;
 }
 

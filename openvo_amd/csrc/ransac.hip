@@ -258,7 +258,7 @@ static int ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, i
         return vo_fail(ctx, VO_E_ARG, "vo_ransac_essential: need n >= %d and 0 < iters <= 4194304", min_n);
     VO_HIP(ctx, hipSetDevice(ctx->device));
     // workspace: points (2 x n x 8 B), E (iters x 72 B), F (iters x 36 B), counts, mask, best
-    const size_t need = (size_t)n * 16 + (size_t)iters * (72 + 36 + 4) + (size_t)n + 4096;
+    const size_t need = (size_t)n * 16 + (size_t)iters * (72 + 36 + 4 + FP_REC_DOUBLES * 8) + (size_t)n + 4096;
     if (ctx->mw->ransac_ws_bytes < need) {
         if (ctx->mw->ransac_ws) (void)hipFree(ctx->mw->ransac_ws);
         ctx->mw->ransac_ws = nullptr; ctx->mw->ransac_ws_bytes = 0;
@@ -267,6 +267,7 @@ static int ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, i
     }
     uint8_t* w = ctx->mw->ransac_ws;
     double* d_E = (double*)w; w += (size_t)iters * 72;
+    double* d_rec = (double*)w; w += (size_t)iters * FP_REC_DOUBLES * 8;       // five-point solver: k_ransac_hyp5 -> k_ransac_roots5
     float* d_p1 = (float*)w; w += (size_t)n * 8;
     float* d_p2 = (float*)w; w += (size_t)n * 8;
     float* d_F = (float*)w; w += (size_t)iters * 36;
@@ -281,7 +282,8 @@ static int ransac_essential(vo_ctx* ctx, const float* pts1, const float* pts2, i
     const float thr2 = thr * thr;
     if (solver == 5) {
         if (int rc5 = hyp5_prepare(ctx)) return rc5;
-        hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), FP_LDS_DOUBLES * sizeof(double), ctx->stream, d_p1, d_p2, n, K, iters, seed, d_E, d_F, nullptr);
+        hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), FP_LDS_DOUBLES * sizeof(double), ctx->stream, d_p1, d_p2, n, K, iters, seed, d_rec, nullptr);
+        hipLaunchKernelGGL(k_ransac_roots5, dim3(div_up(iters, 8)), dim3(256), 0, ctx->stream, d_rec, K, iters, d_E, d_F);
     }
     else
         hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, d_p1, d_p2, n, K, iters, seed, d_E, d_F, nullptr);
@@ -329,7 +331,7 @@ static int mono_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, c
 {
     const int min_n = solver == 5 ? 6 : 8;
     const int nq = a.n_kp;
-    const size_t need = (size_t)iters * (72 + 36 + 4) + (size_t)nq + 4096;
+    const size_t need = (size_t)iters * (72 + 36 + 4 + FP_REC_DOUBLES * 8) + (size_t)nq + 4096;
     if (ctx->mw->ransac_ws_bytes < need) {
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->mw->ransac_ws) (void)hipFree(ctx->mw->ransac_ws);
@@ -339,6 +341,7 @@ static int mono_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, c
     }
     uint8_t* w = ctx->mw->ransac_ws;
     double* d_E = (double*)w; w += (size_t)iters * 72;
+    double* d_rec = (double*)w; w += (size_t)iters * FP_REC_DOUBLES * 8;       // five-point solver: k_ransac_hyp5 -> k_ransac_roots5
     float* d_F = (float*)w; w += (size_t)iters * 36;
     int32_t* d_counts = (int32_t*)w; w += (size_t)iters * 4;
     o.d_best = (int32_t*)w; w += 256;
@@ -357,7 +360,8 @@ static int mono_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, c
         const float thr2 = thr * thr;
         if (solver == 5) {
             if (int rc5 = hyp5_prepare(ctx)) return rc5;
-            hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), FP_LDS_DOUBLES * sizeof(double), ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, K, iters, seed, d_E, d_F, ctx->mw->m_count);
+            hipLaunchKernelGGL(k_ransac_hyp5, dim3(div_up(iters, 64)), dim3(64), FP_LDS_DOUBLES * sizeof(double), ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, K, iters, seed, d_rec, ctx->mw->m_count);
+            hipLaunchKernelGGL(k_ransac_roots5, dim3(div_up(iters, 8)), dim3(256), 0, ctx->stream, d_rec, K, iters, d_E, d_F);
         }
         else
             hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, K, iters, seed, d_E, d_F, ctx->mw->m_count);

@@ -108,9 +108,13 @@ __device__ __forceinline__ void chan_bounds(const uint8_t* img, int W, int H, in
 
 __global__ void k_sgbm_planes(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
                               int ft, uint32_t* __restrict__ PL, uint32_t* __restrict__ PR, int* __restrict__ d2key,
-                              int* __restrict__ sw_ctl, int sw_ctl_words, uint32_t* __restrict__ c_dummy, int dummy_words, uint32_t P2_2)
+                              int* __restrict__ sw_ctl, int sw_ctl_words, uint32_t* __restrict__ c_dummy, int dummy_words, uint32_t P2_2,
+                              uint8_t* __restrict__ keepL, uint8_t* __restrict__ keepR)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    // (a few hundred workgroups walking the rows instead of one per 256 pixels: a short kernel's workgroups each have to win a
+    // slot from the dispatcher against the other pairs' sweeps)
+    for (int y = blockIdx.y; y < H; y += gridDim.y) {
     // one row of cells holding P2 (= cost 0) right behind the used part of the cost volume: what the diagonal sweep reads for a
     // pixel outside the image (such a pixel carries the border state exactly when its cost is zero)
     if (y == 1 && blockIdx.x == 0 && (int)threadIdx.x < dummy_words) c_dummy[threadIdx.x] = P2_2;
@@ -120,6 +124,9 @@ __global__ void k_sgbm_planes(const uint8_t* __restrict__ L, const uint8_t* __re
         for (int i = threadIdx.x; i < sw_ctl_words; i += blockDim.x) sw_ctl[i] = 0;
     if (x >= W) return;
     size_t i = (size_t)y * W + x, plane = (size_t)W * H;
+    // (inputs resident in HBM and already rectified: the pair is read where it lies and its copy into the frame slot -- which
+    // ORB and the downloads read later -- is written here instead of by two copy commands in front of this kernel)
+    if (keepL) { keepL[i] = L[i]; keepR[i] = R[i]; }
     if (d2key) d2key[i] = D2_EMPTY;   // uniquenessRatio >= 100 only (k_sgbm_wta keeps disp2 in HBM): its candidates start empty
     for (int c = 0; c < 2; c++) {
         int v, lo, hi;
@@ -131,6 +138,7 @@ __global__ void k_sgbm_planes(const uint8_t* __restrict__ L, const uint8_t* __re
         PR[(size_t)(c * 3 + 0) * plane + i] = (uint32_t)v | ((uint32_t)v1 << 16);
         PR[(size_t)(c * 3 + 1) * plane + i] = (uint32_t)lo | ((uint32_t)lo1 << 16);
         PR[(size_t)(c * 3 + 2) * plane + i] = (uint32_t)hi | ((uint32_t)hi1 << 16);
+    }
     }
 }
 
@@ -1116,21 +1124,32 @@ __global__ void __launch_bounds__(512) k_sgbm_post_rows(const int* __restrict__ 
     // LDS row r holds image row y0 - 1 + r (rows outside the image are never read: the median clamps its row indices)
     for (int i = tid; i < R * W; i += nt) { d2[i] = D2_EMPTY; d1[i] = (int16_t)g.invalid16; }
     __syncthreads();
-    for (int r = 0; r < R; r++) {
-        const int y = y0 - 1 + r;
-        if (y < 0 || y >= H) continue;                        // (block-uniform)
-        for (int x1 = tid; x1 < g.W1; x1 += nt) {
-            const int ximg = x1 + g.minX1;
-            const size_t o = (size_t)y * W + ximg;
-            const int a = aux0[o];
+    // (four records per thread in flight: the two loads of a pixel are independent of each other and of the other pixels')
+    const int items = R * g.W1;
+    for (int i0 = tid; i0 < items; i0 += 4 * nt) {
+        int a[4], rr[4], xi[4];
+        uint32_t nb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + k * nt;
+            rr[k] = i / g.W1;
+            xi[k] = i - rr[k] * g.W1 + g.minX1;
+            const int y = y0 - 1 + rr[k];
+            const bool ok = i < items && y >= 0 && y < H;
+            const size_t o = ok ? (size_t)y * W + xi[k] : 0;
+            a[k] = aux0[o];
+            nb[k] = (uint32_t)aux1[o];
+            if (!ok) rr[k] = -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (rr[k] < 0) continue;
+            const int ximg = xi[k], r = rr[k];
             int out = g.invalid16;
-            if (a >= 0) {
-                const int minS = a >> 8, best = a & 255;
+            if (a[k] >= 0) {
+                const int minS = a[k] >> 8, best = a[k] & 255;
                 int dd = best * 16;
-                if (best > 0 && best < g.D - 1) {
-                    const uint32_t n = (uint32_t)aux1[o];
-                    dd = wta_subpixel(best, minS, (int)(n >> 16), (int)(n & 0xFFFFu));
-                }
+                if (best > 0 && best < g.D - 1) dd = wta_subpixel(best, minS, (int)(nb[k] >> 16), (int)(nb[k] & 0xFFFFu));
                 out = dd + g.minD * 16;
                 // disp2: lowest cost wins, ties go to the pixel OpenCV scans first (largest x)
                 atomicMin(&d2[r * W + ximg - best - g.minD], (minS << 16) | (0xFFFF - ximg));
@@ -1301,11 +1320,12 @@ __global__ void __launch_bounds__(256) k_ccl_rows(const int16_t* __restrict__ im
 __global__ void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int maxSize, int* __restrict__ L,
                              int* __restrict__ runlen)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W || y + 1 >= H) return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= W) return;
+    for (int y = blockIdx.y; y + 1 < H; y += gridDim.y) {
     const int i = y * W + x;
     const int v = img[i], u = img[i + W];
-    if (v == newVal || u == newVal || abs(v - u) > maxDiff) return;
+    if (v == newVal || u == newVal || abs(v - u) > maxDiff) continue;
     const int a = L[i], b = L[i + W];
     bool head_a = x == 0, head_b = x == 0, joined_left = false;
     if (x > 0) {
@@ -1314,18 +1334,19 @@ __global__ void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int 
         head_b = u1 == newVal || abs(u - u1) > maxDiff;
         joined_left = v1 != newVal && u1 != newVal && abs(v1 - u1) <= maxDiff && !head_a && !head_b;   // same two runs, one column earlier
     }
-    if (joined_left) return;
+    if (joined_left) continue;
     // a head pixel's label may already point at an ancestor: its own index is the run head
     const int ha = head_a ? i : a, hb = head_b ? i + W : b;
     const int la = ((volatile int*)runlen)[ha], lb = ((volatile int*)runlen)[hb];
     const bool big_a = (la & ~RUN_TOUCH) > maxSize, big_b = (lb & ~RUN_TOUCH) > maxSize;
-    if (big_a && big_b) return;
+    if (big_a && big_b) continue;
     if (big_a != big_b) {
         const int hs = big_a ? hb : ha, ls = big_a ? lb : la;
         if (!(ls & RUN_TOUCH)) atomicOr(&runlen[hs], RUN_TOUCH);
-        return;
+        continue;
     }
     uf_union(L, a, b);
+    }
 }
 
 // component sizes: every run head (recognised geometrically -- after unions a head's label may
@@ -1333,29 +1354,31 @@ __global__ void k_ccl_vmerge(const int16_t* __restrict__ img, int W, int H, int 
 __global__ void k_ccl_sizes(const int16_t* __restrict__ img, int W, int H, int newVal, int maxDiff, int maxSize,
                             int* __restrict__ L, const int* __restrict__ runlen, int* __restrict__ size)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= W) return;
+    for (int y = blockIdx.y; y < H; y += gridDim.y) {
     const int i = y * W + x;
     const int v = img[i];
-    if (v == newVal) return;
+    if (v == newVal) continue;
     const bool start = x == 0 || img[i - 1] == newVal || abs(v - img[i - 1]) > maxDiff;
-    if (!start) return;
+    if (!start) continue;
     const int root = uf_find_halve(L, i);
     L[i] = root;   // flatten: k_ccl_apply then needs two hops (pixel -> run head -> root)
     // only "size <= maxSize" is ever asked, and the counter only grows: once it is past the limit
     // further adds are pointless (this removes the contention on the few huge components)
-    if (((volatile int*)size)[root] > maxSize) return;
+    if (((volatile int*)size)[root] > maxSize) continue;
     const int len = runlen[i];
     atomicAdd(&size[root], (len & ~RUN_TOUCH) + ((len & RUN_TOUCH) ? maxSize + 1 : 0));
+    }
 }
 
 __global__ void k_ccl_apply(int16_t* __restrict__ img, int n, int newVal, int maxSize, const int* __restrict__ L,
                             const int* __restrict__ size)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int r = L[i];
-    if (r >= 0 && size[uf_find(L, r)] <= maxSize) img[i] = (int16_t)newVal;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = L[i];
+        if (r >= 0 && size[uf_find(L, r)] <= maxSize) img[i] = (int16_t)newVal;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1529,20 +1552,20 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
     return VO_OK;
 }
 
-static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h);
+static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t* srcL, const uint8_t* srcR);
 // rows per block of k_sgbm_post_rows: (RB + 2) rows of disp1 (2 bytes per pixel) and disp2 keys (4 bytes) must fit in LDS
 static uint32_t pk_rep_host(int v) { return (uint32_t)(v & 0xFFFF) * 0x00010001u; }
-static int post_rows_per_block(int w) { return std::min(8, (int)(150 * 1024 / ((size_t)w * 6)) - 2); }
+static int post_rows_per_block(int w) { return std::min(6, (int)(150 * 1024 / ((size_t)w * 6)) - 2); }
 
 // The SGBM workspaces (planes, C, S volumes, CCL arrays) are shared by the main and the look-ahead
 // stream: a run on one stream must not start before the previous run -- possibly on the other
 // stream -- has finished.  An event chain orders them on the device without blocking the host.
-int sgbm_run(vo_ctx* ctx, FrameSlot& f, int w, int h)
+int sgbm_run(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t* srcL, const uint8_t* srcR)
 {
     if (ctx->ws->done_valid) VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ws->done, 0));
     if (++ctx->sweep_gen_next <= 0) ctx->sweep_gen_next = 1;     // this run's generation: never 0 (FrameSlot::sweep_word)
     f.disp_gen = ctx->sweep_gen_next;
-    int rc = sgbm_run_impl(ctx, f, w, h);
+    int rc = sgbm_run_impl(ctx, f, w, h, srcL, srcR);
     if (ctx->ws->done) {
         VO_HIP(ctx, hipEventRecord(ctx->ws->done, ctx->stream));
         ctx->ws->done_valid = true;
@@ -1550,10 +1573,10 @@ int sgbm_run(vo_ctx* ctx, FrameSlot& f, int w, int h)
     return rc;
 }
 
-static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h)
+static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t* srcL, const uint8_t* srcR)
 {
-    const uint8_t* const dL = f.left;
-    const uint8_t* const dR = f.right;
+    const uint8_t* const dL = srcL ? srcL : f.left;
+    const uint8_t* const dR = srcL ? srcR : f.right;
     int16_t* const d_disp = f.disp16;
     const SgbmEff& e = ctx->sg;
     if (!e.set) return vo_fail(ctx, VO_E_STATE, "vo_set_sgbm has not been called");
@@ -1585,9 +1608,9 @@ static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h)
     {
         StageTimer t(ctx, VO_T_SGBM_COST);
         const int dbg = ctx->tune_diag_dbg;          // development only (VO_DIAG_DEBUG): 4 / 8 / 16 / 32 skip the cost / W+E / diagonal / post stage
-        hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
+        hipLaunchKernelGGL(k_sgbm_planes, dim3(div_up(w, 256), std::min(h, 128)), dim3(256), 0, ctx->stream, dL, dR, w, h, g.ftzero,
                            ctx->ws->planesL, ctx->ws->planesR, (g.ur >= 100 || post_rows_per_block(w) < 1) ? ctx->ws->ccl_size : nullptr, ctx->ws->sw_ctl, ctx->sw_ctl_words,
-                           (uint32_t*)(ctx->ws->C + vol), g.Dp / 2, pk_rep_host(g.P2));
+                           (uint32_t*)(ctx->ws->C + vol), g.Dp / 2, pk_rep_host(g.P2), srcL ? f.left : nullptr, srcL ? f.right : nullptr);
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
         const int TY = ctx->tune_sweep_ty;
         const int nw = bx / 64;
@@ -1650,9 +1673,9 @@ static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h)
                 hipLaunchKernelGGL(k_ccl_rows, dim3(h), dim3(256), 0, ctx->stream, d_disp, w, newVal, maxDiff, ctx->ws->ccl_label, ctx->ws->ccl_runlen, ctx->ws->ccl_size);
         }
         if (speckle) {
-            hipLaunchKernelGGL(k_ccl_vmerge, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_runlen);
-            hipLaunchKernelGGL(k_ccl_sizes, dim3(div_up(w, 256), h), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_runlen, ctx->ws->ccl_size);
-            hipLaunchKernelGGL(k_ccl_apply, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_disp, n, newVal, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_size);
+            hipLaunchKernelGGL(k_ccl_vmerge, dim3(div_up(w, 256), std::min(h, 128)), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_runlen);
+            hipLaunchKernelGGL(k_ccl_sizes, dim3(div_up(w, 256), std::min(h, 128)), dim3(256), 0, ctx->stream, d_disp, w, h, newVal, maxDiff, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_runlen, ctx->ws->ccl_size);
+            hipLaunchKernelGGL(k_ccl_apply, dim3(std::min(div_up(n, 256), 1024)), dim3(256), 0, ctx->stream, d_disp, n, newVal, e.speckleWindow, ctx->ws->ccl_label, ctx->ws->ccl_size);
         }
         VO_CHECK_LAUNCH(ctx);
     }

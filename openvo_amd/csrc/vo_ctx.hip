@@ -133,7 +133,12 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     ctx->max_w = max_w; ctx->max_h = max_h; ctx->max_disp = max_disp; ctx->max_kp = max_kp;
     if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s)", prop.name, prop.gcnArchName);
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        // (some driver stacks report no marketing name: say what the device is by its architecture and size then)
+        char generic[96];
+        snprintf(generic, sizeof(generic), "AMD GPU, %d CUs, %.0f GB", prop.multiProcessorCount, (double)prop.totalGlobalMem / 1e9);
+        snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s)", prop.name[0] ? prop.name : generic, prop.gcnArchName);
+    }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete ctx; return VO_E_HIP; }
     (void)hipEventCreateWithFlags(&ctx->ws->done, hipEventDisableTiming);
     (void)hipEventCreate(&ctx->ev0);
@@ -653,7 +658,10 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
             if (p.mid_valid) (void)hipStreamWaitEvent(ctx->stream, p.mid, 0);
         }
         rc = slot_before_overwrite(ctx, f);
-        if (!rc) {
+        // a rectified gray pair that already lies in HBM needs no ingest step of its own: the SGBM run's first kernel reads it
+        // where it lies and leaves the slot's copy behind (two copy commands less per pair on the engine's queue)
+        const bool in_place = kind == hipMemcpyDeviceToDevice && preprocessed && channels == 1;
+        if (!rc && !in_place) {
             StageTimer t(ctx, VO_T_UPLOAD);
             const bool pinned_src = hs != nullptr || from_host;   // (the library's own pinned staging either way)
             rc = ingest(ctx, 0, srcL, w, h, channels, preprocessed, f.left, ctx->stage_in, kind, pinned_src);
@@ -672,7 +680,7 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
         if (!rc && ctx->fault_prefetch > 0 && --ctx->fault_prefetch == 0)
             rc = vo_fail(ctx, VO_E_STATE, "injected failure (VO_FAULT_PREFETCH) inside the engine scope");
 #endif
-        if (!rc) rc = sgbm_run(ctx, f, w, h);
+        if (!rc) rc = in_place ? sgbm_run(ctx, f, w, h, srcL, srcR) : sgbm_run(ctx, f, w, h);
         if (!rc && ctx->la_orb) {
             const int* q = ctx->la_orb_params;
             rc = orb_slot_enqueue(ctx, f, q[0], q[1], q[2], q[3]);

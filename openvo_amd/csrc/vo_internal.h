@@ -272,7 +272,6 @@ struct vo_ctx {
 };
 
 int vo_fail(vo_ctx* ctx, int code, const char* fmt, ...);
-
 #define VO_HIP(ctx, call)                                                               \
     do {                                                                                \
         hipError_t e__ = (call);                                                        \
@@ -316,7 +315,9 @@ __global__ void k_ratio_compact(const int32_t* idx, const int32_t* dist, int nq,
                                 int32_t* q_out, int32_t* t_out, float* xyq_out, float* xyt_out, int32_t* m_out);   // pose / clique scratch for nq query keypoints
 
 // implemented in the per-stage files
-int sgbm_run(vo_ctx* ctx, FrameSlot& f, int w, int h);     // f.left, f.right (w x h) -> f.disp16; gives the run its generation
+// f.left, f.right (w x h) -> f.disp16; gives the run its generation.  srcL / srcR (both or neither): the rectified gray pair lies
+// THERE in device memory and f.left / f.right still have to receive their copy (done by the run's first kernel)
+int sgbm_run(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t* srcL = nullptr, const uint8_t* srcR = nullptr);
 // VO_E_SWEEP when the disparity the slot holds comes from a run whose sweep gave up a hand-off.  Only meaningful once the host
 // has waited for work that depends on that run (a stream or event synchronisation).
 int slot_health(vo_ctx* ctx, const FrameSlot& f, int slot);

@@ -1,17 +1,31 @@
 #!/bin/bash
-# Collect the judged profile set on the GPU box into gpurun_out/prof_<tag>/ : kernel stats of the bench
-# command, and the two PMC passes.  usage: tools/profile_round.sh TAG     (run via gpurun)
+# The judged profile set of a round, on the GPU box -> gpurun_out/prof_<tag>/ ; reduce it with tools/pmc_summary.py <tag>.
+#   usage (via gpurun): tools/profile_round.sh TAG [quick|full] [WORKLOAD]
+#   stats/        rocprofv3 --kernel-trace --stats of `bench.py --steps 96 --warmup 12` (16 pairs in flight) -> kernel_stats
+#   alone/        the same with VO_LOOKAHEAD=0 VO_POSE_AHEAD=0 (one pair at a time: every kernel alone on the GPU)
+#   fetch/ write/ the two HBM-traffic PMC passes (separate runs, --pmc with --kernel-trace only)
+#   occ/          SQ occupancy / issue / stall counters (full only)
 set -e
-tag=${1:-r01}
+tag=${1:-r04}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=24   # in the shell: under rocprofv3 the runtime starts before python can set it
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 48 --warmup 6 --cpu-pairs 0 > $out/bench_under_rocprof.json 2> $out/stats.err
+WL=${3:-C2}
+B="python3 $GRAFT_REPO_ROOT/bench.py --cpu-pairs 0 --no-post --no-other --repeats 1 --workload $WL"
+N1=96; W1=12
+if [ "$WL" != "C2" ]; then N1=24; W1=4; fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- $B --steps $N1 --warmup $W1 > $out/bench_under_rocprof.json 2> $out/stats.err
+VO_LOOKAHEAD=0 VO_POSE_AHEAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/alone -o bench -- $B --steps 24 --warmup 4 > $out/bench_alone_under_rocprof.json 2> $out/alone.err
 echo "stats done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-pairs 0 > /dev/null 2> $out/fetch.err
-echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-pairs 0 > /dev/null 2> $out/write.err
-echo "write done"
-ls $out/*
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o pmc -- $B --steps 6 --warmup 2 > /dev/null 2> $out/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o pmc -- $B --steps 6 --warmup 2 > /dev/null 2> $out/write.err
+echo "traffic done"
+if [ "$2" != "quick" ]; then
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/occ -o pmc -- $B --steps 6 --warmup 2 > /dev/null 2> $out/occ.err
+  echo "occupancy done"
+fi
+# (the per-dispatch traces are large and not needed by the summary)
+find $out -name "*kernel_trace.csv" -delete
+find $out -name "*.csv" | head -40
