@@ -340,3 +340,27 @@ def test_point_clouds_generic_path_matches_reference_golden_g7():
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
         n_pts += len(p1)
     assert n_pts > 80
+
+
+def test_image_too_wide_for_the_fused_post_kernel_takes_the_separate_passes(oracle):
+    """k_sgbm_post_rows keeps (RB + 2) image rows of disp1 / disp2 in LDS; an image wider than ~8500 pixels does not fit even
+    one output row per block and falls back to the same steps as separate passes over HBM (k_sgbm_fin, k_lr_median3,
+    k_ccl_rows).  Same bits either way."""
+    from openvo_amd import _native
+    w, h = 8704, 48
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (h, w + 16), dtype=np.uint8)
+    base = ((base.astype(np.int32) + np.roll(base, 1, 1) + np.roll(base, 1, 0)) // 3).astype(np.uint8)   # a little smoothing: real matches
+    L, R = np.ascontiguousarray(base[:, 5:5 + w]), np.ascontiguousarray(base[:, :w])                         # disparity 5 px
+    p = dict(minDisparity=0, numDisparities=16, blockSize=5, P1=100, P2=400, disp12MaxDiff=1, preFilterCap=31,
+             uniquenessRatio=10, speckleWindowSize=60, speckleRange=2)
+    ctx = _native.Context(0, w, 64, 16, 100)
+    try:
+        ctx.set_sgbm(p, 0)
+        got = ctx.sgbm_compute_host(L, R)
+        assert ctx.sgbm_last_schedule() in (_native.SCHED_DIAG, _native.SCHED_DIAG_RAGGED)
+    finally:
+        ctx.close()
+    ref = oracle.sgbm_compute(L, R, p, 0)
+    assert np.array_equal(got, ref), "%d pixels differ" % int((got != ref).sum())
+    assert (ref == 80).mean() > 0.5            # 5 px x 16: the planted shift is what was found
