@@ -351,7 +351,7 @@ def test_image_too_wide_for_the_fused_post_kernel_takes_the_separate_passes(orac
     rng = np.random.default_rng(5)
     base = rng.integers(0, 256, (h, w + 16), dtype=np.uint8)
     base = ((base.astype(np.int32) + np.roll(base, 1, 1) + np.roll(base, 1, 0)) // 3).astype(np.uint8)   # a little smoothing: real matches
-    L, R = np.ascontiguousarray(base[:, 5:5 + w]), np.ascontiguousarray(base[:, :w])                         # disparity 5 px
+    L, R = np.ascontiguousarray(base[:, :w]), np.ascontiguousarray(base[:, 5:5 + w])                         # L(x) = R(x - 5): disparity 5 px
     p = dict(minDisparity=0, numDisparities=16, blockSize=5, P1=100, P2=400, disp12MaxDiff=1, preFilterCap=31,
              uniquenessRatio=10, speckleWindowSize=60, speckleRange=2)
     ctx = _native.Context(0, w, 64, 16, 100)
@@ -363,4 +363,28 @@ def test_image_too_wide_for_the_fused_post_kernel_takes_the_separate_passes(orac
         ctx.close()
     ref = oracle.sgbm_compute(L, R, p, 0)
     assert np.array_equal(got, ref), "%d pixels differ" % int((got != ref).sum())
-    assert (ref == 80).mean() > 0.5            # 5 px x 16: the planted shift is what was found
+    assert (ref == 80).mean() > 0.3            # 5 px x 16: the planted shift is what was found
+
+
+def test_orb_selection_with_a_flood_of_score_ties(oracle):
+    """retainBest keeps every candidate that ties with the n-th best (orb.cpp / KeyPointsFilter).  On a periodic texture (an
+    8 x 8 tile repeated over the image) every corner exists 4800 times with one FAST score and one Harris response: the
+    survivors of level 0 (3744 of them: quota 109 + its ties) no longer fit the fused selection kernel's LDS lists
+    (ORB_SEL_CAP = 2048) and that level falls back to the global scratch arrays inside the same launch, while the other
+    levels stay in LDS.  Same keypoints, responses, angles and descriptors as the oracle either way."""
+    from openvo_amd import _native
+    h, w = 480, 640
+    tile = np.random.default_rng(0).choice([30, 220], size=(8, 8), p=[0.6, 0.4]).astype(np.uint8)
+    img = np.tile(tile, (h // 8, w // 8))
+    ctx = _native.Context(0, 704, 512, 64, 8000)           # capacity for the ties: far more than nfeatures keypoints come back
+    try:
+        got = ctx.orb_host(img, None, 500)
+    finally:
+        ctx.close()
+    ref = oracle.orb_detect_and_compute(img, None, 500, cap=40000)
+    assert np.bincount(ref["octave"], minlength=8)[0] > 2048, np.bincount(ref["octave"])    # level 0: the ties were kept (quota 109)
+    assert np.array_equal(got["octave"], ref["octave"])
+    assert np.array_equal(got["xy"].view(np.uint32), ref["xy"].view(np.uint32))
+    assert np.array_equal(got["response"].view(np.uint32), ref["response"].view(np.uint32))
+    assert np.array_equal(got["angle"].view(np.uint32), ref["angle"].view(np.uint32))
+    assert np.array_equal(got["desc"], ref["desc"])

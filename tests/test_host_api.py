@@ -184,3 +184,26 @@ def test_device_image_behaves_like_the_numpy_view_the_reference_returns():
     # the lazy fused mask evaluates to the same array
     assert np.array_equal(np.asarray(DisparityMask(f, 4, 100)), m)
     assert "DeviceImage(disp" in repr(d)
+
+
+def test_image_arguments_are_validated_before_a_pointer_reaches_native_code():
+    """HxW and HxWx3 pass (HxWx1 is squeezed); anything else -- HxWx4, a scalar, mismatched shapes -- raises ValueError in
+    Python.  The native side reads w * h * channels bytes from the pointer it is given (on a staging thread, where no
+    exception could surface), so the check has to happen here."""
+    from openvo_amd._native import _image_pair
+    g = np.zeros((6, 8), np.uint8)
+    l, r, ch = _image_pair(g, g.copy())
+    assert ch == 1 and l.shape == (6, 8) and l.flags["C_CONTIGUOUS"]
+    l, r, ch = _image_pair(g[:, :, None], g)                     # HxWx1 is the same image
+    assert ch == 1 and l.shape == (6, 8)
+    l, r, ch = _image_pair(np.zeros((6, 8, 3), np.uint8), np.zeros((6, 8, 3), np.int64))
+    assert ch == 3 and r.dtype == np.uint8
+    l, r, ch = _image_pair(np.zeros((6, 16), np.uint8)[:, ::2], g)   # non-contiguous views are copied
+    assert l.flags["C_CONTIGUOUS"] and l.shape == (6, 8)
+    for bad in (np.zeros((6, 8, 4), np.uint8), np.zeros((6, 8, 2), np.uint8), np.zeros(5, np.uint8), np.zeros((2, 3, 4, 3), np.uint8)):
+        with pytest.raises(ValueError):
+            _image_pair(bad, bad)
+    with pytest.raises(ValueError):
+        _image_pair(g, np.zeros((6, 9), np.uint8))
+    with pytest.raises(ValueError):
+        _image_pair(g, np.zeros((6, 8, 3), np.uint8))
