@@ -16,6 +16,10 @@
 #define EDGE VO_ORB_EDGE
 #define HALF_PATCH VO_ORB_HALF_PATCH
 #define FAST_T 20
+#ifndef ORB_FAST_TH
+#define ORB_FAST_TH 32
+#endif
+// rows per tile of k_orb_fast_nms (a multiple of 4: each of the block's four waves judges TH / 4 rows)
 
 struct LevelDev {
     int w, h;
@@ -360,45 +364,9 @@ __global__ void __launch_bounds__(256) k_orb_pyramid(const LevelsDev L, const Py
 // ---------------------------------------------------------------------------------------
 // FAST-9/16
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int w)
+// cornerScore<16> of OpenCV's FAST: the largest threshold for which the pixel is still a corner; d[k] = centre - ring pixel k
+__device__ __forceinline__ int fast_corner_score(const int* d)
 {
-    // ring offsets (dx,dy), OpenCV order
-    const int rx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
-    const int ry[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
-    const int v = p[0];
-    // a run of 9 on the 16-ring covers at least two of the four compass points (0, 4, 8, 12): when fewer than two of them are
-    // darker and fewer than two brighter the pixel cannot be a corner.  Most of an image fails this test; a wavefront whose
-    // 64 pixels all fail skips the other twelve loads and the arc test (the branch is wave-uniform).
-    {
-        int nd = 0, nb = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k += 4) {
-            const int q = p[ry[k] * w + rx[k]];
-            nd += q < v - FAST_T;
-            nb += q > v + FAST_T;
-        }
-        if (__ballot(nd >= 2 || nb >= 2) == 0ull) return 0;
-    }
-    int d[16];
-    unsigned dark = 0, bright = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int q = p[ry[k] * w + rx[k]];
-        d[k] = v - q;
-        dark |= (unsigned)(q < v - FAST_T) << k;
-        bright |= (unsigned)(q > v + FAST_T) << k;
-    }
-    // >= 9 contiguous set bits on the 16-ring
-    auto run9 = [](unsigned m) -> bool {
-        unsigned r = m | (m << 16);
-        unsigned a = r & (r >> 1);      // runs of 2
-        a = a & (a >> 2);               // runs of 4
-        a = a & (a >> 4);               // runs of 8
-        a = a & (r >> 8);               // runs of 9
-        return (a & 0xFFFFu) != 0;
-    };
-    if (!run9(dark) && !run9(bright)) return 0;
-    // cornerScore<16>: largest threshold for which the pixel is still a corner
     int a0 = FAST_T;
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
@@ -421,18 +389,34 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ p, int 
 }
 
 // FAST score + 3x3 non-max suppression (strict >) + pixel mask + image border in one pass; survivors are
-// appended per level.  Block = 4 waves, tile = 64 columns x 16 rows of the border-free interior: the scores
-// of the tile and its 1-pixel halo go through LDS only (no score image), wave w then judges rows 4w..4w+3.
+// appended per level.  Block = 4 waves, tile = 64 columns x ORB_FAST_TH rows of the border-free interior: the scores
+// of the tile and its 1-pixel halo go through LDS only (no score image), wave w then judges rows w TH/4 .. (w + 1) TH/4 - 1.
 // The survivors of the whole tile reserve their slots with ONE returning global atomic (a per-wave atomic
 // on a single counter serialises at ~12 ns each).
+// Scoring is three passes over shrinking LDS lists instead of one divergent function per pixel (round 4: the kernel was
+// 10 % of the pipeline's vector instructions -- a wave paid for the 16-pixel ring and the 200-instruction corner score as soon
+// as ONE of its 64 pixels needed them, which in a textured image is nearly every wave):
+//   A  every pixel of the tile + halo: the four compass points of the ring (a run of 9 covers at least two of them: fewer than
+//      two darker and fewer than two brighter => not a corner); the survivors (10-25 %) are listed
+//   B  the listed pixels, densely packed over the lanes: the ring's dark / bright masks and the run-of-9 test; survivors listed
+//   C  the few real corners: cornerScore
+// The tile's pixels (+ the ring's reach) are staged in LDS once: a ring read is one ds_read_u8 at a constant offset.
 __global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev L, const uint8_t* __restrict__ pimg,
                                                       const uint8_t* __restrict__ pmask, int with_mask, int32_t* __restrict__ cand_pos,
                                                       float* __restrict__ cand_resp, int32_t* __restrict__ cnt)
 {
-    constexpr int TW = 64, TH = 16, SW = TW + 2, SH = TH + 2, SP = SW + 2;   // padded LDS row
+    constexpr int TW = 64, TH = ORB_FAST_TH, RW = TH / 4, SW = TW + 2, SH = TH + 2, SP = SW + 2;   // padded LDS row
+    constexpr int IW = SW + 6, IH = SH + 6, IP = IW + 4;                    // staged pixels: the scored region + 3 on each side
+    constexpr int NPX = SW * SH;
     __shared__ uint8_t s_sc[SH * SP];
-    __shared__ int s_cnt[16];
+    __shared__ uint8_t s_img[IH * IP];
+    __shared__ uint16_t s_listA[NPX], s_listB[NPX];
+    __shared__ int s_nA, s_nB;
+    __shared__ int s_cnt[TH];
     __shared__ int s_base;
+    // ring offsets (dx,dy), OpenCV order
+    constexpr int rx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+    constexpr int ry[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
     // A compact one-dimensional grid walks the tiles of all levels (level-major): a (tiles_x, tiles_y, levels) grid sized for
     // level 0 launched 6720 workgroups at config 2 of which 60 % returned at once -- and every workgroup of a short kernel has
     // to win a slot from the dispatcher against the other pairs' sweeps.
@@ -443,6 +427,7 @@ __global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev L, const u
         const int iw = L.l[l].w - 2 * EDGE, ih = L.l[l].h - 2 * EDGE;
         tiles_before[l + 1] = tiles_before[l] + (iw > 0 && ih > 0 ? ((iw + TW - 1) / TW) * ((ih + TH - 1) / TH) : 0);
     }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int tile = blockIdx.x; tile < tiles_before[NL]; tile += gridDim.x) {
     int lvl = 0;
 #pragma unroll
@@ -452,21 +437,95 @@ __global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev L, const u
     const int x0 = (tl % tpr) * TW + EDGE, y0 = (tl / tpr) * TH + EDGE;
     const int xlim = d.w - EDGE + 1, ylim = d.h - EDGE + 1;   // scores are needed up to one pixel past the interior
     const uint8_t* img = pimg + d.off;
-    for (int i = threadIdx.x; i < SW * SH; i += blockDim.x) {
+    // stage rows y0 - 4 .. y0 + TH + 4, columns x0 - 4 .. x0 + TW + 4 (x0, y0 >= EDGE: the low side is inside the image; the
+    // high side is clamped -- a pixel whose ring would leave the image is beyond xlim / ylim and never scored)
+    for (int i = threadIdx.x; i < IH * IW; i += blockDim.x) {
+        const int ty = i / IW, tx = i - ty * IW;
+        const int x = min(x0 - 4 + tx, d.w - 1), y = min(y0 - 4 + ty, d.h - 1);
+        s_img[ty * IP + tx] = img[(size_t)y * d.w + x];
+    }
+    for (int i = threadIdx.x; i < SH * SP; i += blockDim.x) s_sc[i] = 0;
+    if (threadIdx.x == 0) { s_nA = 0; s_nB = 0; }
+    __syncthreads();
+    // pass A
+    for (int i0 = 0; i0 < NPX; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
         const int ty = i / SW, tx = i - ty * SW;
-        const int x = x0 - 1 + tx, y = y0 - 1 + ty;
-        int s = 0;
-        if (x < xlim && y < ylim) s = fast_score_at(img + (size_t)y * d.w + x, d.w);   // x, y >= EDGE - 1 >= 3 always
-        s_sc[ty * SP + tx] = (uint8_t)s;
+        bool pass = false;
+        if (i < NPX && x0 - 1 + tx < xlim && y0 - 1 + ty < ylim) {   // x, y >= EDGE - 1 >= 3 always
+            const uint8_t* c = s_img + (ty + 3) * IP + tx + 3;
+            const int v = c[0];
+            int nd = 0, nb = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) {
+                const int q = c[ry[k] * IP + rx[k]];
+                nd += q < v - FAST_T;
+                nb += q > v + FAST_T;
+            }
+            pass = nd >= 2 || nb >= 2;
+        }
+        const unsigned long long bal = __ballot(pass);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_nA, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (pass) s_listA[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = x0 + lane;
-    int sc[4];
-    unsigned long long bal[4];
+    // pass B
+    const int nA = s_nA;
+    for (int e0 = 0; e0 < nA; e0 += blockDim.x) {
+        const int e = e0 + threadIdx.x;
+        bool pass = false;
+        int i = 0;
+        if (e < nA) {
+            i = s_listA[e];
+            const int ty = i / SW, tx = i - ty * SW;
+            const uint8_t* c = s_img + (ty + 3) * IP + tx + 3;
+            const int v = c[0];
+            unsigned dark = 0, bright = 0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int ty = wv * 4 + r, y = y0 + ty;
+            for (int k = 0; k < 16; k++) {
+                const int q = c[ry[k] * IP + rx[k]];
+                dark |= (unsigned)(q < v - FAST_T) << k;
+                bright |= (unsigned)(q > v + FAST_T) << k;
+            }
+            // >= 9 contiguous set bits on the 16-ring
+            auto run9 = [](unsigned m) -> bool {
+                unsigned r = m | (m << 16);
+                unsigned a = r & (r >> 1);      // runs of 2
+                a = a & (a >> 2);               // runs of 4
+                a = a & (a >> 4);               // runs of 8
+                a = a & (r >> 8);               // runs of 9
+                return (a & 0xFFFFu) != 0;
+            };
+            pass = run9(dark) || run9(bright);
+        }
+        const unsigned long long bal = __ballot(pass);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_nB, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (pass) s_listB[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    // pass C
+    const int nB = s_nB;
+    for (int e = threadIdx.x; e < nB; e += blockDim.x) {
+        const int i = s_listB[e];
+        const int ty = i / SW, tx = i - ty * SW;
+        const uint8_t* c = s_img + (ty + 3) * IP + tx + 3;
+        const int v = c[0];
+        int dd[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) dd[k] = v - (int)c[ry[k] * IP + rx[k]];
+        s_sc[ty * SP + tx] = (uint8_t)fast_corner_score(dd);
+    }
+    __syncthreads();
+    const int x = x0 + lane;
+    int sc[RW];
+    unsigned long long bal[RW];
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+        const int ty = wv * RW + r, y = y0 + ty;
         int s = 0;
         if (x < d.w - EDGE && y < d.h - EDGE) {
             const uint8_t* q = s_sc + (ty + 1) * SP + lane + 1;
@@ -476,20 +535,20 @@ __global__ void __launch_bounds__(256) k_orb_fast_nms(const LevelsDev L, const u
         }
         sc[r] = s;
         bal[r] = __ballot(s != 0);
-        if (lane == 0) s_cnt[wv * 4 + r] = __popcll(bal[r]);
+        if (lane == 0) s_cnt[wv * RW + r] = __popcll(bal[r]);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         int tot = 0;
-        for (int k = 0; k < 16; k++) { const int c = s_cnt[k]; s_cnt[k] = tot; tot += c; }  // exclusive prefix
+        for (int k = 0; k < TH; k++) { const int c = s_cnt[k]; s_cnt[k] = tot; tot += c; }  // exclusive prefix
         s_base = tot ? atomicAdd(&cnt[CNT_CAND + lvl], tot) : 0;
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < RW; r++) {
         if (sc[r]) {
-            const int y = y0 + wv * 4 + r;
-            const int slot = s_base + s_cnt[wv * 4 + r] + __popcll(bal[r] & ((1ull << lane) - 1ull));
+            const int y = y0 + wv * RW + r;
+            const int slot = s_base + s_cnt[wv * RW + r] + __popcll(bal[r] & ((1ull << lane) - 1ull));
             cand_pos[d.cand_off + slot] = y * d.w + x;
             cand_resp[d.cand_off + slot] = (float)sc[r];
         }
@@ -987,7 +1046,7 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
     }
     int fast_tiles = 0;
     for (int l = 0; l < NL; l++)
-        if (Lh->l[l].w > 2 * EDGE && Lh->l[l].h > 2 * EDGE) fast_tiles += div_up(Lh->l[l].w - 2 * EDGE, 64) * div_up(Lh->l[l].h - 2 * EDGE, 16);
+        if (Lh->l[l].w > 2 * EDGE && Lh->l[l].h > 2 * EDGE) fast_tiles += div_up(Lh->l[l].w - 2 * EDGE, 64) * div_up(Lh->l[l].h - 2 * EDGE, ORB_FAST_TH);
     hipLaunchKernelGGL(k_orb_fast_nms, dim3(std::max(1, std::min(fast_tiles, 2048))), dim3(256), 0, ctx->stream, dL,
                        ctx->orbws->pyr_img, ctx->orbws->pyr_mask, with_mask, ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->counters);
     // after the select, cand_* hold the per-level final lists; candB_* are scratch
