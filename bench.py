@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 # switches the reference's own optional stages ON (more work per pair, not less): see `deviations` in the output.
 ODO_KW = dict(nfeatures=500, match_threshold=0.8, rigidity_threshold=0.1, outlier_threshold=0.02,
               preprocessed_frames=True, min_matches=10)
+SHADER_GHZ = 2.4            # measured under load: tools/clock_probe.hip (2.38-2.41)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DEVIATIONS = {
     "odometer": "rigidity_threshold=0.1, outlier_threshold=0.02 instead of the reference defaults 0 / 0: with the plain fit a "
@@ -62,7 +63,7 @@ def main():
     ap.add_argument("--mix-stages", action="store_true",
                     help="diagnostic: one more steady pass with HIP events around EVERY stage on its own stream -> `stage_ms_per_pair_in_mix` "
                          "(a stage's latency beside the other pairs' kernels; the events themselves cost some throughput)")
-    ap.add_argument("--steady", type=int, default=480,
+    ap.add_argument("--steady", type=int, default=960,
                     help="pairs of the untimed-for-`value` steady-state pass reported as `steady_state` (0 = skip)")
     args = ap.parse_args()
 
@@ -282,12 +283,13 @@ def bench_stereo(args, group, device, workload, K, W, light):
         P = 8 if workload == "C4" else 5
         alg_bytes = 2.0 * cells * npaths          # the int16 cost volume read once per direction the kernel covers (3)
         survey_bytes = 2.0 * cells * (1 + P)      # A_sgbm = 2 B * V * (1 + P) for the whole pair
-        traffic, per_pair, traffic_rev = None, None, "unknown"
+        traffic, per_pair, traffic_rev, valu_pp = None, None, "unknown", None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
                 traffic, per_pair = tj.get("dominant_kernel_bytes_per_launch"), tj.get("sgbm_bytes_per_pair")
+                valu_pp = tj.get("valu_wave_instructions_per_pair")
                 traffic_rev = tj.get("source", "unknown")
                 if not isinstance(per_pair, (int, float)):        # (a profile file of an older layout)
                     per_pair = None
@@ -325,6 +327,14 @@ def bench_stereo(args, group, device, workload, K, W, light):
         if per_pair:
             roof["aggregate"]["measured_traffic_bytes_per_pair"] = per_pair
             roof["aggregate"]["measured_traffic_gb_per_s"] = round(per_pair * value / world / 1e9, 1)
+        if isinstance(valu_pp, (int, float)) and valu_pp > 0:
+            # the other roof of this integer pipeline: a wave64 packed-integer / DPP instruction holds its SIMD for 4 cycles
+            issue_peak = 1024 * SHADER_GHZ * 1e9 / 4.0            # wave-instructions per second the 1024 SIMDs can issue
+            roof["aggregate"]["vector_issue"] = {
+                "wave_instructions_per_pair": int(valu_pp), "per_second": round(valu_pp * value / world, 0),
+                "peak_per_second": issue_peak, "frac": round(valu_pp * value / world / issue_peak, 4),
+                "note": "SQ_INSTS_VALU of every kernel of a pair (committed profile, not measured in this run) x pairs/s against 1024 "
+                        "SIMDs x %.1f GHz / 4 cycles per wave64 instruction: the job sits between its two roofs, closer to this one" % SHADER_GHZ}
         if copy_gbs is not None:
             ceil = max(copy_gbs.values())
             roof["copy_ceiling"] = {"unit": "GB/s", "bytes_counted": "read + written", **copy_gbs,

@@ -58,16 +58,24 @@ with open(os.path.join(dst, "%s_pmc_%s_summary.csv" % (tag, low)), "w") as fh:
     for r in rows:
         fh.write("\"%s\",%d,%.1f,%.1f,%d\n" % (r[0], r[1], r[2], r[3], int((2 * r[2] + r[3]) * 1024)))
 per_pair = int(round((2 * tot_f + tot_w) * 1024))
+o, meta = load("occ")
+valu_per_pair = None
+if o:
+    # vector instructions of ALL kernels of a pair (SQ_INSTS_VALU counts wave-instructions), from the occupancy pass
+    n_occ = max(len(v) for (c, k), v in o.items() if c == "SQ_INSTS_VALU" and k.startswith(("k_sgbm_planes", "k_orb_pyramid")))
+    valu_per_pair = int(sum(sum(v) for (c, k), v in o.items() if c == "SQ_INSTS_VALU" and k.startswith("k_")) / n_occ)
 json.dump({"workload": wl,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 6 --warmup 2 --cpu-pairs 0 --no-post` "
                      "(tools/profile_round.sh %s), MI355X, default schedule (W + E volume, diagonal sweep)" % tag,
            "correction": "gfx950: FETCH_SIZE counts wide coalesced (16 B/lane) reads at half -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
            "kernel": dom[0] if dom else None, "dominant_kernel_bytes_per_launch": dom[1] if dom else None,
            "sgbm_bytes_per_pair": per_pair, "FETCH_SIZE_KB_raw_per_pair": round(tot_f), "WRITE_SIZE_KB_raw_per_pair": round(tot_w),
-           "pairs_profiled": npairs}, open(os.path.join(dst, "traffic_%s.json" % wl), "w"), indent=1)
-print("SGBM bytes per pair: %.3f GB over %d pairs; dominant kernel %s" % (per_pair / 1e9, npairs, dom))
+           "pairs_profiled": npairs,
+           "valu_wave_instructions_per_pair": valu_per_pair,
+           "valu_source": "SQ_INSTS_VALU summed over every kernel of the pipeline (the occupancy pass of the same script), per pair"},
+          open(os.path.join(dst, "traffic_%s.json" % wl), "w"), indent=1)
+print("SGBM bytes per pair: %.3f GB over %d pairs; dominant kernel %s; vector wave-instructions per pair %s" % (per_pair / 1e9, npairs, dom, valu_per_pair))
 
-o, meta = load("occ")
 if o:
     with open(os.path.join(dst, "%s_occupancy_%s.csv" % (tag, low)), "w") as fh:
         fh.write("kernel,dispatches,grid_threads,workgroup,vgprs,lds_bytes,waves,waves_per_simd_if_all_resident,valu_busy_frac_of_wave_cycles,"
