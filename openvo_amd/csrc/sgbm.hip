@@ -198,7 +198,8 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
                                                         SgbmGeom g, int TY, int16_t* __restrict__ C)
 {
     constexpr int WIN = 2 * SW2 + 1, NC = XT + 2 * SW2;
-    extern __shared__ uint32_t s_ring[];  // [waves][WIN][XT][64]
+    extern __shared__ uint32_t s_ring[];  // staging of the interior strips only: [waves][12][NJ]
+    uint32_t ringv[WIN][XT];              // the vertical window's ring: registers (the row loop is unrolled by WIN, so every index is a constant)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int dpl = threadIdx.x;                  // disparity pair index (padded layout)
     const bool pad = 2 * dpl >= g.D;
@@ -211,7 +212,6 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
     const int tbx = tile % gx, tby = tile / gx;
     const int xa = tbx * XT, ya = tby * TY;
     const size_t plane = (size_t)g.W * g.H;
-    uint32_t* ring = s_ring + (size_t)wv * WIN * XT * 64 + lane;
     const int yend = min(ya + TY, g.H);
     const int nrows = (yend - ya) + 2 * SW2;       // rows ya-2 .. yend+1 (clamped)
     const int lane0_d = 2 * 64 * wv;               // disparity of this wave's lane 0 (relative to minD)
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
             typedef __attribute__((address_space(3))) w2 lds_w2;
             // staging layout: [parity][j][the six planes] -- a lane fetches the six planes of its position with three 8-byte reads
             // at immediate offsets; consecutive lanes are 6 words apart, which spreads every 32-lane pass over all 64 banks
-            lds_w* const stage = (lds_w*)(s_ring + (size_t)(blockDim.x >> 6) * WIN * XT * 64) + (size_t)wv * 12 * NJ;
+            lds_w* const stage = (lds_w*)s_ring + (size_t)wv * 12 * NJ;
             lds_w* const st_wr = stage + lane * 6;                     // + parity * NJ * 6  (+ 64 * 6 for the tail lanes)
             const lds_w* const st_rd = stage + (63 - lane) * 6;        // + ((k & 1) * NJ + (k >> 1)) * 6
             const bool tail = lane < NJ - 64;
@@ -270,8 +270,11 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
                 pl1 = lw.y;
             };
             fetch(0);
-            for (int rr = 0; rr < nrows; rr++) {
-                const int slot = rr % WIN;
+            for (int rr0 = 0; rr0 < nrows; rr0 += WIN) {
+#pragma unroll
+            for (int slot = 0; slot < WIN; slot++) {
+                const int rr = rr0 + slot;
+                if (rr >= nrows) break;                                // (uniform)
 #pragma unroll
                 for (int h = 0; h < 3; h++) {
                     *(lds_w2*)(st_wr + 2 * h) = (w2){ pfm[2 * h].x, pfm[2 * h + 1].x };
@@ -302,10 +305,9 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
 #pragma unroll
                 for (int j = 0; j < XT; j++) {
                     if (j > 0) s = pk_sub(pk_add(s, pc[j + WIN - 1]), pc[j - 1]);
-                    uint32_t* cell = ring + (size_t)(slot * XT + j) * 64;
-                    if (rr >= WIN) acc[j] = pk_sub(acc[j], *cell);
+                    if (rr >= WIN) acc[j] = pk_sub(acc[j], ringv[slot][j]);
                     acc[j] = pk_add(acc[j], s);
-                    *cell = s;
+                    ringv[slot][j] = s;
                 }
                 if (rr >= WIN - 1) {
                     const int y = ya + rr - (WIN - 1);
@@ -318,13 +320,17 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
                         __builtin_amdgcn_raw_buffer_store_b32(pad ? MAXC2 : acc[j], rC, 2 * dpl < g.Dp ? 4 * dpl : 0x7FFFFFF0, j * g.Dp * 2, 0);
                 }
             }
+            }
             return;
         }
     }
 
-    for (int rr = 0; rr < nrows; rr++) {
+    for (int rr0 = 0; rr0 < nrows; rr0 += WIN) {
+#pragma unroll
+    for (int slot = 0; slot < WIN; slot++) {
+        const int rr = rr0 + slot;
+        if (rr >= nrows) break;                                        // (uniform)
         const int r = min(max(ya - SW2 + rr, 0), g.H - 1);
-        const int slot = rr % WIN;
         const size_t rowi = (size_t)r * g.W;
         const uint32_t plr0 = PL[(rowi + xrun) * 2], plr1 = PL[(rowi + xrun) * 2 + 1];
         uint32_t run[6];
@@ -373,10 +379,9 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
 #pragma unroll
         for (int j = 0; j < XT; j++) {
             if (j > 0) s = pk_sub(pk_add(s, pc[j + WIN - 1]), pc[j - 1]);
-            uint32_t* cell = ring + (size_t)(slot * XT + j) * 64;
-            if (rr >= WIN) acc[j] = pk_sub(acc[j], *cell);   // the row leaving the window
+            if (rr >= WIN) acc[j] = pk_sub(acc[j], ringv[slot][j]);   // the row leaving the window
             acc[j] = pk_add(acc[j], s);
-            *cell = s;
+            ringv[slot][j] = s;
         }
         if (rr >= WIN - 1) {
             const int y = ya + rr - (WIN - 1);
@@ -387,6 +392,7 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
                     *(uint32_t*)(C + ((size_t)y * g.W1 + x1) * g.Dp + 2 * dpl) = pad ? MAXC2 : acc[j];
             }
         }
+    }
     }
 }
 
@@ -1616,7 +1622,7 @@ static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t*
         const int nw = bx / 64;
 #define LAUNCH_SWEEP(XT, SW)                                                                                                   \
     hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(8 * div_up(div_up(g.W1, XT) * div_up(h, TY), 8)), dim3(bx),            \
-                       (size_t)nw * ((2 * SW + 1) * XT * 64 + 12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->ws->planesL, ctx->ws->planesR, g, TY, ctx->ws->C)
+                       (size_t)nw * (12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->ws->planesL, ctx->ws->planesR, g, TY, ctx->ws->C)
         if (dbg & 4) {
         } else
         switch (g.SW2) {
