@@ -20,6 +20,7 @@
 #define ORB_FAST_TH 32
 #endif
 // rows per tile of k_orb_fast_nms (a multiple of 4: each of the block's four waves judges TH / 4 rows)
+static_assert(ORB_FAST_TH % 4 == 0 && ORB_FAST_TH >= 4 && (64 + 2) * (ORB_FAST_TH + 2) < 65536, "k_orb_fast_nms: tile height");
 
 struct LevelDev {
     int w, h;
