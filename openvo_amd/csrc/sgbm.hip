@@ -1609,6 +1609,10 @@ static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t*
     const size_t vol = (size_t)g.W1 * h * g.Dp;
     if (vol > ctx->vol_cells || e.D > 256)
         return vo_fail(ctx, VO_E_CAP, "cost volume %zu cells exceeds the capacity given to vo_create (or D > 256)", vol);
+    // the diagonal sweep addresses a volume through one buffer descriptor: 32-bit byte offsets, the top 256 reserved as the
+    // out-of-range value (3840 x 2160 with D = 256 is 3.96 GB and fits; 4096 x 2304 with D = 256 does not)
+    if (((size_t)g.W1 * h + 1) * g.Dp * 2 >= 0xFFFFFF00ull)
+        return vo_fail(ctx, VO_E_CAP, "cost volume of %zu bytes exceeds the 4 GiB a volume kernel addresses", ((size_t)g.W1 * h + 1) * g.Dp * 2);
     const PathPlan plan = make_plan(g, e.mode);
     ctx->last_cells = (int64_t)g.W1 * h * g.D;
     {

@@ -404,3 +404,63 @@ def test_mono_unpredicted_request_while_predictions_are_in_flight():
         odo._ctx.close()
     for (a, ca, na, la, Ta), (b, cb, nb, lb, Tb) in zip(chains[0], chains[3]):
         assert a == b and ca == cb and na == nb and la == lb and np.array_equal(Ta, Tb)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sgbm_4k_matches_the_oracle_fixture(mode):
+    """Beyond every BASELINE size: 3840 x 2160 with D = 256 -- a 3.96 GB cost volume, so that every 32-bit byte offset inside the
+    volume kernels (buffer descriptors, scalar offsets) is exercised past 2^31 -- in MODE_SGBM and in MODE_HH (the reverse sweep
+    writes a second volume).  The oracle needs minutes and tens of GB for this frame, so its result travels as a fixture
+    (tests/golden/make_oracle_4k.py: SHA-256 of the whole disparity image + eight of its rows per mode; an ORACLE-derived
+    regression fixture, not a reference-derived one); the pair itself is rebuilt from integer arithmetic (tests/big_pair.py).
+    Also: the same call twice gives the same bytes, the ground plane's disparity law holds, and a size whose volume would pass
+    4 GiB is refused, not truncated."""
+    import hashlib, os
+    from tests.big_pair import pair
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "o1_sgbm_4k.npz"))
+    w, h = int(fx["w"]), int(fx["h"])
+    p = {str(k): int(v) for k, v in zip(fx["param_names"], fx["params"])}
+    L, R, d = pair(w, h)
+    ctx = _native.Context(0, 4096, 2304, p["numDisparities"], 500)
+    try:
+        ctx.set_sgbm(p, mode)
+        got = ctx.sgbm_compute_host(L, R)
+        again = ctx.sgbm_compute_host(L, R)
+        if mode == 0:
+            big = np.zeros((2304, 4096), np.uint8)
+            with pytest.raises(_native.VoError, match="4 GiB"):
+                ctx.sgbm_compute_host(big, big)
+    finally:
+        ctx.close()
+    assert got.shape == (h, w) and np.array_equal(got, again)
+    rows = [int(r) for r in fx["rows"]]
+    for r, want in zip(rows, fx["disp_rows_mode%d" % mode]):
+        assert np.array_equal(got[r], want), "row %d: %d pixels differ" % (r, int((got[r] != want).sum()))
+    assert hashlib.sha256(got.tobytes()).digest() == fx["sha256_mode%d" % mode].tobytes()
+    mid = got[h // 2][got[h // 2] >= 0] / 16.0
+    assert abs(np.median(mid) - d[h // 2]) < 0.5
+
+
+@pytest.mark.parametrize("nfeatures", [2000, 8000])
+def test_orb_4k_matches_the_oracle_fixture(nfeatures):
+    """ORB on a 3840 x 2160 image (the pyramid's cones, the FAST tiles and the candidate lists at four times config 5's pixel
+    count), through the fused selection kernel (nfeatures <= 2000) and through the three-launch one: keypoints, responses,
+    angles, octaves and descriptors bit for bit the oracle's -- whose run on this image takes 100 s per call, so it travels as
+    digests of every output array (tests/golden/make_oracle_4k.py orb; oracle-derived, not reference-derived)."""
+    import hashlib, os
+    from tests.big_pair import pair
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "o2_orb_4k.npz"))
+    L, _, _ = pair(int(fx["w"]), int(fx["h"]), seed=int(fx["seed"]))
+    ctx = _native.Context(0, 3840, 2160, 64, nfeatures)
+    try:
+        got = ctx.orb_host(L, None, nfeatures)
+    finally:
+        ctx.close()
+    n = nfeatures
+    assert len(got["xy"]) == int(fx["count_%d" % n]) >= 0.9 * n
+    assert np.array_equal(np.bincount(got["octave"], minlength=8), fx["per_level_%d" % n])
+    assert np.array_equal(got["xy"][:64].view(np.uint32), fx["head_xy_%d" % n].view(np.uint32))
+    assert np.array_equal(got["desc"][:64], fx["head_desc_%d" % n])
+    DT = dict(xy=np.float32, response=np.float32, angle=np.float32, octave=np.int32, desc=np.uint8)
+    for k in ("xy", "response", "angle", "octave", "desc"):
+        assert hashlib.sha256(np.ascontiguousarray(got[k], dtype=DT[k]).tobytes()).digest() == fx["sha256_%s_%d" % (k, n)].tobytes(), k
