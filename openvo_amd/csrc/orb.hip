@@ -1003,8 +1003,8 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
                        const int16_t* d_disp16, int disp_stride, int min_d16, int max_d16, const uint8_t* d_mask, int mask_stride)
 {
     fs->has_kp = false;
-    if (w < 2 * EDGE + 8 || h < 2 * EDGE + 8) {
-        // every level is cleared by runByImageBorder
+    if (w <= 2 * EDGE || h <= 2 * EDGE) {
+        // level 0 has no pixel inside the border, and no smaller level has one: runByImageBorder clears every level
         *fs->n_kp_host = 0;
         return VO_OK;
     }

@@ -980,7 +980,9 @@ __device__ __forceinline__ void wta_pixel(const LV<NP>& S, const SgbmGeom& g, in
     if (live && l16 == 0) {
         const int ximg = x1 + g.minX1;
         int out = g.invalid16;
-        if (!row_viol) {
+        // (minS == 32767: every sum saturated -- OpenCV's search starts from minS = SHRT_MAX with `<`, finds nothing, and the pixel
+        //  comes out as (minD - 1) * 16 = INVALID)
+        if (!row_viol && minS < MAXC) {
             int dd = best * 16;
             if (best > 0 && best < g.D - 1) dd = wta_subpixel(best, minS, myS[best - 1], myS[best + 1]);
             out = dd + g.minD * 16;

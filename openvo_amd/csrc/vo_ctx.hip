@@ -329,6 +329,14 @@ extern "C" int vo_set_sgbm(vo_ctx* ctx, int minDisparity, int numDisparities, in
     e.speckleWindow = speckleWindowSize; e.speckleRange = speckleRange; e.mode = mode;
     if (e.SW2 > 5) return vo_fail(ctx, VO_E_ARG, "blockSize > 11 is not supported");
     if (e.P2 > 8000 || e.ftzero > 127) return vo_fail(ctx, VO_E_ARG, "P2 > 8000 or preFilterCap > 127 would overflow int16 costs");
+    // a path cost is at most the block's largest matching cost + P2; OpenCV keeps it in a short and wraps beyond 32767 (its
+    // results are then garbage): refused here rather than reproduced
+    {
+        const int side = 2 * e.SW2 + 1, cmax = side * side * (2 * e.ftzero + 63);
+        if (cmax + e.P2 > 32767)
+            return vo_fail(ctx, VO_E_ARG, "blockSize %d with preFilterCap %d and P2 %d lets a path cost reach %d: beyond the int16 OpenCV computes in",
+                           side, e.ftzero, e.P2, cmax + e.P2);
+    }
     e.set = true;
     return VO_OK;
 }

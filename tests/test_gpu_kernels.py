@@ -388,3 +388,101 @@ def test_orb_selection_with_a_flood_of_score_ties(oracle):
     assert np.array_equal(got["response"].view(np.uint32), ref["response"].view(np.uint32))
     assert np.array_equal(got["angle"].view(np.uint32), ref["angle"].view(np.uint32))
     assert np.array_equal(got["desc"], ref["desc"])
+
+
+@pytest.mark.parametrize("w,h", [(63, 300), (300, 63), (64, 256), (1400, 66), (66, 1100), (67, 69), (62, 200)])
+def test_orb_thin_images_keep_the_pixels_inside_the_border(oracle, w, h):
+    """An image 63 .. 69 pixels wide or high still has 1 .. 7 columns / rows inside ORB's 31-pixel border at level 0
+    (runByImageBorder keeps x in [31, w - 31)): the extraction must not give up on it (round 4: it returned nothing below
+    70 pixels).  62 pixels: nothing is left, like OpenCV.  With and without a mask, few and many features."""
+    from openvo_amd import _native
+    from tests.big_pair import canvas
+    img = canvas(w, h, seed=w * 7 + h)
+    stripe = np.zeros((h, w), np.uint8)
+    stripe[:, ::3] = 255
+    stripe[::5] = 0
+    ctx = _native.Context(0, 1408, 1104, 64, 3000)
+    try:
+        total = 0
+        for nf in (7, 500, 3000):
+            for m in (None, stripe):
+                g = ctx.orb_host(img, m, nf)
+                r = oracle.orb_detect_and_compute(img, m, nf, cap=20000)
+                assert len(g["xy"]) == len(r["xy"]), (nf, m is not None)
+                total += len(r["xy"])
+                for k in ("xy", "response", "angle"):
+                    assert np.array_equal(g[k].view(np.uint32), r[k].view(np.uint32)), (k, nf)
+                assert np.array_equal(g["octave"], r["octave"]) and np.array_equal(g["desc"], r["desc"])
+        assert (total > 0) == (min(w, h) > 62)
+    finally:
+        ctx.close()
+
+
+def test_sgbm_every_sum_saturated_is_invalid_like_opencv(oracle):
+    """P1 = 1000, P2 = 8000, blockSize 11, MODE_HH: where nothing matches, all 8 path costs of a pixel are large and every
+    summed cost saturates at 32767.  OpenCV's winner search starts from minS = SHRT_MAX and compares with `<`: it finds nothing,
+    bestDisp stays -1 and the pixel comes out as (minD - 1) * 16 -- INVALID -- whatever the uniqueness ratio (here 0).  Found by
+    the parameter fuzz below (round 4: the kernels returned disparity 0 there)."""
+    from openvo_amd import _native
+    from tests.big_pair import pair
+    p = dict(minDisparity=0, numDisparities=32, blockSize=11, P1=1000, P2=8000, disp12MaxDiff=1000, preFilterCap=1,
+             uniquenessRatio=0, speckleWindowSize=0, speckleRange=0)
+    L, R, _ = pair(333, 150, dmin=1, dmax=30, seed=3)
+    R = np.ascontiguousarray(R[::-1])                   # rows swapped top to bottom: nothing matches anywhere
+    ctx = _native.Context(0, 512, 200, 32, 64)
+    try:
+        hit = 0
+        for mode in (0, 1):
+            ctx.set_sgbm(p, mode)
+            got = ctx.sgbm_compute_host(L, R)
+            ref = oracle.sgbm_compute(L, R, p, mode)
+            assert np.array_equal(got, ref), "mode %d: %d pixels differ" % (mode, int((got != ref).sum()))
+            hit += int((ref[:, 40:] == -16).sum())
+        assert hit > 0                                   # the case is really exercised: invalid pixels right of the left band
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_sgbm_parameter_fuzz_against_the_oracle(oracle, seed):
+    """150 random draws per seed over everything StereoSGBM_create takes -- image size, numDisparities 16 .. 256, minDisparity
+    -32 .. 40, blockSize 1 .. 11, P1 / P2 down to 0 / equal and up to the limit, preFilterCap 0 .. 127, uniquenessRatio 0 ..
+    100, speckle window 0 .. larger than the image, speckle range 0 .. 100, disp12MaxDiff -1 .. 1000, both modes; textured,
+    unmatched and textureless pairs: bit-exact, or refused with the documented message (a path cost beyond int16)."""
+    from openvo_amd import _native
+    from tests.big_pair import pair
+    rng = np.random.default_rng(seed)
+    ctxs, refused = {}, 0
+    try:
+        for it in range(150):
+            w = int(rng.choice([180, 257, 333, 400, 512])); h = int(rng.choice([64, 97, 150, 200]))
+            D = int(rng.choice([16, 32, 48, 64, 96, 128, 160, 256]))
+            if w - D < 20:
+                D = 16
+            mind = int(rng.choice([-32, -1, 0, 0, 7, 40]))
+            P1 = int(rng.choice([0, 1, 8, 200, 1000]))
+            p = dict(minDisparity=mind, numDisparities=D, blockSize=int(rng.choice([1, 3, 5, 5, 7, 9, 11])), P1=P1,
+                     P2=min(8000, P1 + int(rng.choice([0, 1, 24, 600, 3000, 7000]))), disp12MaxDiff=int(rng.choice([-1, 0, 1, 5, 1000])),
+                     preFilterCap=int(rng.choice([0, 1, 15, 31, 63, 100, 127])), uniquenessRatio=int(rng.choice([0, 5, 15, 50, 99, 100])),
+                     speckleWindowSize=int(rng.choice([0, 10, 100, 100000])), speckleRange=int(rng.choice([0, 1, 2, 10, 100])))
+            mode = int(rng.integers(0, 2))
+            L, R, _ = pair(w, h, dmin=max(1, mind + 1), dmax=max(2, min(D + mind - 2, w // 3)), seed=int(rng.integers(1, 1000)))
+            if rng.random() < 0.2:
+                R = np.ascontiguousarray(L[:, ::-1])
+            if rng.random() < 0.15:
+                L = np.full_like(L, 77); R = np.full_like(R, 77)
+            if D not in ctxs:
+                ctxs[D] = _native.Context(0, 512, 200, D, 64)
+            try:
+                ctxs[D].set_sgbm(p, mode)
+            except _native.VoError as e:
+                assert "beyond the int16" in str(e), (p, str(e))
+                refused += 1
+                continue
+            got = ctxs[D].sgbm_compute_host(L, R)
+            ref = oracle.sgbm_compute(L, R, p, mode)
+            assert np.array_equal(got, ref), "draw %d %s mode %d: %d pixels differ" % (it, p, mode, int((got != ref).sum()))
+        assert refused < 30
+    finally:
+        for c in ctxs.values():
+            c.close()
