@@ -486,3 +486,90 @@ def test_sgbm_parameter_fuzz_against_the_oracle(oracle, seed):
     finally:
         for c in ctxs.values():
             c.close()
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_small_operator_fuzz_against_the_oracle(oracle, seed):
+    """Hamming kNN-2 (1 .. 2000 descriptors a side, random / four distinct descriptors = ties everywhere / all-zero against
+    all-one / near-copies) + the ratio filter at 0 .. 1.5, bilinear lookups in float images with inf / -inf / nan taps, at
+    integer positions and at the last pixel, reprojectImageTo3D with zero and negative disparities, BGR -> gray, the rigid
+    clique at thresholds 0 .. 1 with repeated and colinear points: bit for bit; Umeyama (1e-9) and Rodrigues (1e-12, rotations
+    by pi and not-quite-rotations included); degenerate fits raise on both sides."""
+    from openvo_amd import _native, calib
+    rng = np.random.default_rng(seed)
+    ctx = _native.Context(0, 640, 480, 64, 2000)
+    try:
+        for it in range(40):
+            nq = int(rng.choice([1, 2, 3, 63, 64, 65, 200, 511, 512, 513, 2000])); nt = int(rng.choice([1, 2, 3, 63, 64, 65, 129, 1000, 2000]))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+            elif kind == 1:
+                base = rng.integers(0, 256, (4, 32), dtype=np.uint8)
+                q = base[rng.integers(0, 4, nq)]; t = base[rng.integers(0, 4, nt)]
+            elif kind == 2:
+                q = np.zeros((nq, 32), np.uint8); t = np.full((nt, 32), 255, np.uint8)
+            else:
+                t = rng.integers(0, 256, (nt, 32), dtype=np.uint8); q = t[rng.integers(0, nt, nq)].copy(); q[:, 0] ^= rng.integers(0, 4, nq).astype(np.uint8)
+            gi, gd = ctx.bf_knn2(q, t)
+            ri, rd = oracle.bf_knn2_hamming(q, t)
+            assert np.array_equal(gi, ri) and np.array_equal(gd, rd), ("knn2", nq, nt, kind)
+            if nt >= 2:
+                for ratio in (0.0, 0.5, 0.8, 1.0, 1.5):
+                    a, b = ctx.ratio_filter(gi, gd, ratio), oracle.ratio_filter(ri, rd, ratio)
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), ("ratio", nq, nt, kind, ratio)
+        for it in range(30):
+            h, w = int(rng.integers(2, 40)), int(rng.integers(2, 50))
+            img = (rng.normal(size=(h, w, 3)) * 50).astype(np.float32)
+            img[rng.random((h, w)) < 0.2] = np.inf
+            img[rng.random((h, w)) < 0.05] = -np.inf
+            img[rng.random((h, w)) < 0.03] = np.nan
+            n = int(rng.integers(1, 300))
+            xy = np.stack([rng.uniform(0, w - 1, n), rng.uniform(0, h - 1, n)], 1).astype(np.float32)
+            xy[: n // 4] = np.floor(xy[: n // 4])
+            xy[0] = [w - 1, h - 1]
+            g, gs = ctx.bilinear_at(img, xy)
+            r, rs = oracle.bilinear_at(img, xy)
+            assert np.array_equal(gs, rs) and np.array_equal(g.view(np.uint32)[rs != 2], r.view(np.uint32)[rs != 2]), ("bilinear", h, w, n)
+        for it in range(15):
+            h, w = int(rng.integers(1, 60)), int(rng.integers(1, 80))
+            disp = (rng.integers(-16, 2000, (h, w)) / 16.0).astype(np.float32)
+            disp[rng.random((h, w)) < 0.1] = 0
+            Q = np.array([[1, 0, 0, -rng.uniform(10, 40)], [0, 1, 0, -rng.uniform(5, 30)], [0, 0, 0, rng.uniform(100, 900)],
+                          [0, 0, 1 / rng.uniform(0.05, 0.6), rng.uniform(-1, 1)]])
+            assert np.array_equal(ctx.reproject_to_3d(disp, Q).view(np.uint32), oracle.reproject_to_3d(disp, Q).view(np.uint32)), ("reproject", h, w)
+            bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            assert np.array_equal(ctx.cvt_bgr2gray(bgr), oracle.bgr2gray(bgr))
+        for it in range(40):
+            n = int(rng.choice([3, 4, 10, 11, 63, 64, 65, 200, 513, 700]))
+            P = (rng.normal(size=(n, 3)) * 5 + [0, 0, 20]).astype(np.float32)
+            Rm = calib.rodrigues_vec_to_mat(rng.uniform(-0.2, 0.2, 3))
+            C = (P @ Rm.T + rng.uniform(-1, 1, 3)).astype(np.float32)
+            out = rng.random(n) < rng.choice([0.0, 0.2, 0.6])
+            C[out] += (rng.normal(size=(int(out.sum()), 3)) * 3).astype(np.float32)
+            if it % 7 == 0:
+                P[:] = P[0]; C[:] = C[0]
+            if it % 11 == 0:
+                P[:, 1:] = 0; C[:, 1:] = 0
+            thr = float(rng.choice([0.0, 0.01, 0.1, 1.0]))
+            assert np.array_equal(np.asarray(ctx.rigid_clique(P, C, thr)) != 0, np.asarray(oracle.rigid_clique(P, C, thr)) != 0), ("clique", n, thr, it)
+            for force in (True, False):
+                res = []
+                for f in (ctx.umeyama, oracle.umeyama):
+                    try:
+                        res.append(f(P, C, force))
+                    except Exception:
+                        res.append(None)
+                assert (res[0] is None) == (res[1] is None), ("umeyama raises on one side only", n, it)
+                if res[0] is not None:
+                    assert np.allclose(res[0][0], res[1][0], rtol=0, atol=1e-9, equal_nan=True), ("umeyama", n, it, force)
+        for it in range(120):
+            Rm = calib.rodrigues_vec_to_mat(rng.normal(size=3) * rng.choice([1e-12, 1e-6, 0.1, 1.0, 3.1, 3.14159]))
+            if it % 9 == 0:
+                Rm = np.diag(rng.permutation([1.0, -1.0, -1.0]))
+            if it % 13 == 0:
+                Rm = Rm + rng.normal(size=(3, 3)) * 1e-3
+            g, r = _native.Context.rodrigues(Rm), oracle.rodrigues(Rm)
+            assert np.allclose(np.asarray(g).ravel(), np.asarray(r).ravel(), rtol=0, atol=1e-12, equal_nan=True), ("rodrigues", it)
+    finally:
+        ctx.close()

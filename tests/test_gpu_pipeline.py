@@ -636,3 +636,42 @@ def test_lookahead_depth_counts_what_is_really_in_flight():
     cam.stage_pairs(c.pairs(0, 4))
     assert ctx.lookahead_depth() == 0
     assert ctx.sgbm_sweep_status() == 0
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_update_sequence_fuzz_against_the_oracle_odometer(seed):
+    """Random odometers (features 50 .. 300, ratio 0.5 .. 0.95, rigidity 0 .. 5, outlier 0 .. 0.5, min_matches 3 .. 100) on a
+    14-frame sequence in which frames are replaced at random by textureless ones ("keypoints"), by jumps to another frame of
+    the sequence ("bigdist" / "rigidity" / "matches"), by pairs with a broken right image (few valid disparities) and by
+    posterised ones: every update()'s result, skip_cause, skipped_frames and chained pose equal the oracle odometer's -- the
+    fused device path, the one-frame-back fallback and the speculative pose steps included."""
+    from oracle.odometer import RefStereoCamera, RefStereoOdometer
+    rng = np.random.default_rng(seed)
+    c = Corridor("T0")
+    base = c.pairs(0, 14)
+    causes = set()
+    for trial in range(5):
+        nfeat = int(rng.choice([50, 150, 300]))
+        kw = dict(nfeatures=nfeat, match_threshold=float(rng.choice([0.5, 0.8, 0.95])), rigidity_threshold=float(rng.choice([0, 0, 0.02, 0.1, 5.0])),
+                  outlier_threshold=float(rng.choice([0, 0, 0.005, 0.02, 0.5])), min_matches=int(rng.choice([3, 10, 40, 100])))
+        cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=nfeat)
+        rcam = RefStereoCamera(cam.Q, cam.valid_region_left, c.sgbm_params())
+        odo = StereoOdometer(cam, preprocessed_frames=True, **kw)
+        rodo = RefStereoOdometer(rcam, preprocessed_frames=True, **kw)
+        for k in range(14):
+            L, R = base[k]
+            r = rng.random()
+            if r < 0.12:
+                L = np.full_like(L, 90); R = np.full_like(R, 90)
+            elif r < 0.22:
+                L, R = base[int(rng.integers(0, 14))]
+            elif r < 0.30:
+                R = np.ascontiguousarray(R[::-1])
+            elif r < 0.36:
+                L = (L.astype(np.int32) // 8 * 8).astype(np.uint8)
+            a, b = odo.update(L, R), rodo.update(L, R)
+            assert a == b and odo.skip_cause == rodo.skip_cause and odo.skipped_frames == rodo.skipped_frames, (trial, k, kw)
+            assert np.allclose(odo.c_T_w, rodo.c_T_w, rtol=0, atol=1e-8), (trial, k, kw)
+            if not a:
+                causes.add(odo.skip_cause)
+    assert len(causes) >= 2                                # the disturbances do exercise the rejection paths
