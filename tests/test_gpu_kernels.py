@@ -573,3 +573,56 @@ def test_small_operator_fuzz_against_the_oracle(oracle, seed):
             assert np.allclose(np.asarray(g).ravel(), np.asarray(r).ravel(), rtol=0, atol=1e-12, equal_nan=True), ("rodrigues", it)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_orb_fuzz_against_the_oracle(oracle, seed):
+    """60 draws per seed: image sizes 63 .. 700 a side, seven kinds of content (blocky noise, white noise, checkerboards and
+    tiled patterns = floods of equal scores, constant, ramps, binary), nfeatures 1 .. 4000 (both selection paths: <= 2000 fused,
+    above in three launches), random / empty masks with values 1 or 255: keypoints, responses, angles, octaves and descriptors
+    bit for bit -- or, when the ties push the count past the context's capacity, the documented refusal."""
+    from openvo_amd import _native
+    from tests.big_pair import canvas
+    rng = np.random.default_rng(seed)
+    ctx = _native.Context(0, 704, 704, 64, 4000)
+    try:
+        compared = 0
+        for it in range(60):
+            w, h = int(rng.integers(63, 700)), int(rng.integers(63, 700))
+            kind = int(rng.integers(0, 7))
+            yy, xx = np.mgrid[0:h, 0:w]
+            if kind == 0:
+                img = canvas(w, h, seed=int(rng.integers(1, 10000)))
+            elif kind == 1:
+                img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            elif kind == 2:
+                img = (((xx // int(rng.integers(2, 9))) + (yy // int(rng.integers(2, 9)))) % 2 * 200 + 20).astype(np.uint8)
+            elif kind == 3:
+                img = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+            elif kind == 4:
+                img = ((xx * 3 + yy * 5) % 256).astype(np.uint8)
+            elif kind == 5:
+                img = np.where(canvas(w, h, seed=int(rng.integers(1, 10000))) > 128, 255, 0).astype(np.uint8)
+            else:
+                t = rng.integers(0, 256, (int(rng.integers(3, 12)), int(rng.integers(3, 12))), dtype=np.uint8)
+                img = np.tile(t, (h // t.shape[0] + 1, w // t.shape[1] + 1))[:h, :w].copy()
+            nf = int(rng.choice([1, 2, 10, 100, 500, 1999, 2000, 2001, 4000]))
+            m, r = None, rng.random()
+            if r < 0.3:
+                m = (rng.random((h, w)) > rng.uniform(0.05, 0.95)).astype(np.uint8) * int(rng.choice([1, 255]))
+            elif r < 0.4:
+                m = np.zeros((h, w), np.uint8)
+            ref = oracle.orb_detect_and_compute(img, m, nf, cap=200000)
+            try:
+                got = ctx.orb_host(img, m, nf)
+            except _native.VoError as e:
+                assert "exceed capacity" in str(e) and len(ref["xy"]) > ctx.kp_cap, (it, str(e))
+                continue
+            compared += 1
+            assert len(got["xy"]) == len(ref["xy"]), (it, w, h, kind, nf)
+            for k in ("xy", "response", "angle"):
+                assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (k, it, w, h, kind, nf)
+            assert np.array_equal(got["octave"], ref["octave"]) and np.array_equal(got["desc"], ref["desc"]), (it, w, h, kind, nf)
+        assert compared >= 50
+    finally:
+        ctx.close()
