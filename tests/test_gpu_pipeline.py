@@ -675,3 +675,69 @@ def test_update_sequence_fuzz_against_the_oracle_odometer(seed):
             if not a:
                 causes.add(odo.skip_cause)
     assert len(causes) >= 2                                # the disturbances do exercise the rejection paths
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_hand_over_fuzz_every_way_of_passing_a_pair_equals_plain_updates(seed):
+    """A 30-pair sequence (consecutive frames, now and then a textureless pair or a repeated one) is handed to one odometer in
+    random chunks, each in a random way -- plain update(L, R); run() at depth 0 / 1 / 3 / 20; pairs staged in HBM and consumed in
+    order; pairs submitted ahead; staged pairs abandoned half way (reset_lookahead, the look-ahead work voided) and finished with
+    plain calls; a foreign compute_3d on the same camera in between -- under a random look-ahead depth (0 / 2 / 7 / 18): every
+    update()'s result, skip_cause, skipped_frames and pose are bit-identical to plain updates on a camera without look-ahead."""
+    rng = np.random.default_rng(seed)
+    c = Corridor("T0")
+    frames = c.pairs(0, 40)
+    flat = (np.full_like(frames[0][0], 90), np.full_like(frames[0][1], 90))
+    kw = dict(rigidity_threshold=0.1, outlier_threshold=0.02, preprocessed_frames=True)
+    for trial in range(4):
+        seq, k = [], 0
+        while len(seq) < 30:
+            r = rng.random()
+            if r < 0.08:
+                seq.append(flat)
+            elif r < 0.14 and seq:
+                seq.append(seq[-1])
+            else:
+                seq.append(frames[k % 40]); k += 1
+        cam0 = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=200)
+        cam0.lookahead = 0
+        ref = StereoOdometer(cam0, nfeatures=200, **kw)
+        want = []
+        for L, R in seq:
+            ok = ref.update(L, R)
+            want.append((ok, ref.skip_cause, ref.skipped_frames, ref.c_T_w.copy()))
+        cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=200)
+        cam.lookahead = int(rng.choice([0, 2, 7, 18]))
+        odo = StereoOdometer(cam, nfeatures=200, **kw)
+        got, log, i = [], [], 0
+        rec = lambda ok: got.append((ok, odo.skip_cause, odo.skipped_frames, odo.c_T_w.copy()))
+        while i < len(seq):
+            op, chunk = int(rng.integers(0, 6)), seq[i:i + int(rng.integers(1, 7))]
+            log.append((op, len(chunk)))
+            if op == 0:
+                for L, R in chunk:
+                    rec(odo.update(L, R))
+            elif op == 1:
+                for ok in odo.run(iter(chunk), depth=int(rng.choice([0, 1, 3, 20]))):
+                    rec(ok)
+            elif op == 2:
+                for s in cam.stage_pairs(chunk):
+                    rec(odo.update(s, None))
+            elif op == 3:
+                for s in [cam.submit(L, R, preprocessed=True) for L, R in chunk]:
+                    rec(odo.update(s, None))
+            elif op == 4:
+                st, half = cam.stage_pairs(chunk), max(1, len(chunk) // 2)
+                for s in st[:half]:
+                    rec(odo.update(s, None))
+                odo.reset_lookahead()
+                for L, R in chunk[half:]:
+                    rec(odo.update(L, R))
+            else:
+                cam.compute_3d(*frames[int(rng.integers(0, 40))], preprocessed=True)
+                for L, R in chunk:
+                    rec(odo.update(L, R))
+            i += len(chunk)
+        assert len(got) == len(want)
+        for j, (a, b) in enumerate(zip(got, want)):
+            assert a[:3] == b[:3] and np.array_equal(a[3], b[3]), (trial, j, a[:3], b[:3], cam.lookahead, log)
