@@ -626,3 +626,60 @@ def test_orb_fuzz_against_the_oracle(oracle, seed):
         assert compared >= 50
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", [61])
+def test_ransac_fuzz_against_the_cpu_restatement(oracle, seed):
+    """Essential-matrix RANSAC (five-point and eight-point) and solvePnP RANSAC on random scenes: 5 .. 3000 correspondences,
+    planar scenes, pure rotations, no motion at all, one correspondence repeated, 0 .. 70 % outliers, 1 .. 300 hypotheses,
+    thresholds 0.1 .. 5 px: every hypothesis' inlier count, the winner, the mask bit for bit, E / [R|t] to 1e-11 / 1e-10; too
+    few points raise on both sides.  (No openVO counterpart: parity against the build's own restatement)"""
+    from openvo_amd import _native, calib
+    rng = np.random.default_rng(seed)
+    K4 = np.array([520.0, 515.0, 320.0, 240.0])
+
+    def scene(n, planar, pure_rot, outl, noise):
+        X = np.stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(4, 20, n)], 1)
+        if planar:
+            X[:, 2] = 8 + 0.1 * X[:, 0]
+        R = calib.rodrigues_vec_to_mat(rng.uniform(-0.1, 0.1, 3))
+        t = np.zeros(3) if pure_rot else rng.uniform(-0.5, 0.5, 3)
+        proj = lambda P: np.stack([K4[0] * P[:, 0] / P[:, 2] + K4[2], K4[1] * P[:, 1] / P[:, 2] + K4[3]], 1)
+        p1, p2 = proj(X), proj(X @ R.T + t) + rng.normal(size=(n, 2)) * noise
+        o = rng.random(n) < outl
+        p2[o] = rng.uniform(0, 640, (int(o.sum()), 2))
+        return X.astype(np.float32), p1.astype(np.float32), p2.astype(np.float32)
+
+    def both(f, g):
+        out = []
+        for fn in (f, g):
+            try:
+                out.append(fn())
+            except Exception:
+                out.append(None)
+        return out
+
+    ctx = _native.Context(0, 640, 480, 64, 4000)
+    try:
+        for it in range(40):
+            n = int(rng.choice([5, 6, 7, 8, 9, 20, 64, 65, 500, 3000]))
+            X, p1, p2 = scene(n, rng.random() < 0.2, rng.random() < 0.2, float(rng.choice([0, 0.2, 0.7])), float(rng.choice([0, 0.3, 2.0])))
+            if it % 10 == 0:
+                p2 = p1.copy()
+            if it % 13 == 0:
+                p1[:] = p1[0]; p2[:] = p2[0]
+            iters, thr, sd = int(rng.choice([1, 63, 64, 65, 300])), float(rng.choice([0.1, 1.0, 5.0])), int(rng.integers(0, 2**31))
+            for solver in (5, 8):
+                g, r = both(lambda: ctx.ransac_essential(p1, p2, K4, iters, thr, sd, want_counts=True, solver=solver),
+                            lambda: oracle.ransac_essential(p1, p2, K4, iters, thr, sd, solver=solver))
+                assert (g is None) == (r is None), ("essential raises on one side only", solver, n)
+                if g is not None:
+                    assert np.array_equal(g["counts"], r["counts"]) and g["best_iter"] == r["best_iter"] and np.array_equal(g["mask"], r["mask"]), (solver, n, it)
+                    assert np.allclose(g["E"], r["E"], rtol=0, atol=1e-11, equal_nan=True), (solver, n, it)
+            g, r = both(lambda: ctx.ransac_pnp(X, p2, K4, iters, thr, sd, want_counts=True), lambda: oracle.ransac_pnp(X, p2, K4, iters, thr, sd))
+            assert (g is None) == (r is None), ("pnp raises on one side only", n)
+            if g is not None:
+                assert np.array_equal(g["counts"], r["counts"]) and g["best_iter"] == r["best_iter"] and np.array_equal(g["mask"], r["mask"]), ("pnp", n, it)
+                assert np.allclose(g["Rt"], r["Rt"], rtol=0, atol=1e-10, equal_nan=True), ("pnp", n, it)
+    finally:
+        ctx.close()

@@ -741,3 +741,19 @@ def test_hand_over_fuzz_every_way_of_passing_a_pair_equals_plain_updates(seed):
         assert len(got) == len(want)
         for j, (a, b) in enumerate(zip(got, want)):
             assert a[:3] == b[:3] and np.array_equal(a[3], b[3]), (trial, j, a[:3], b[:3], cam.lookahead, log)
+
+
+def test_abi_misuse_returns_a_status_and_never_crashes():
+    """Every context-taking entry point with a NULL context, NULL data pointers, hostile integers (-1, INT_MIN, INT_MAX, slot
+    28 ...) and in the wrong order on a fresh context: a status code every time, never a fault -- in a process of its own so
+    that a crash would be this test's failure, not the runner's end.  Only harmless calls may report success."""
+    import os, subprocess, sys
+    script = os.path.join(os.path.dirname(__file__), "abi_misuse.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    last = r.stdout.strip().splitlines()[-1].split()
+    assert last[0] == "survived" and int(last[1]) > 300
+    harmless = {"vo_bf_knn2_hamming", "vo_enable_timing", "vo_get_timings", "vo_host_stage_wait", "vo_lookahead_drop", "vo_set_lookahead_orb",
+                "vo_set_roi", "vo_sgbm_last_geometry", "vo_synchronize", "vo_lookahead_depth", "vo_sgbm_last_schedule", "vo_sgbm_sweep_status",
+                "vo_slot_ready", "vo_sgbm_sweep_stats", "vo_stage_pairs_alloc"}
+    assert set(last[2:]) <= harmless, set(last[2:]) - harmless
