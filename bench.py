@@ -249,10 +249,14 @@ def bench_stereo(args, group, device, workload, K, W, light):
         cam.lookahead = la
     if not (args.no_post or light) and not args.from_host and world == 1:
         # PCIe-inclusive rate (never the reported value): the frames that follow in the same sequence, handed over as host
-        # numpy arrays -- 8 untimed pairs, then 96 timed ones whatever K is (a 20-pair window would mostly time the start
-        # of the staging thread and the pipeline's fill)
-        nh = 96
-        hframes = c.pairs(first + n_unique, 8 + nh)
+        # numpy arrays -- 8 untimed pairs, then 480 timed ones whatever K is (a 20-pair window would mostly time the start
+        # of the staging thread and the pipeline's fill): 96 further frames of the sequence, walked forwards and backwards
+        nh, nr = 480, 96
+        hframes = c.pairs(first + n_unique, 8 + nr)
+        hwalk = list(range(nr))
+        while len(hwalk) < nh:
+            hwalk += list(range(nr - 2, -1, -1)) + list(range(1, nr))
+        hwalk = hwalk[:nh]
         # (the odometers of the earlier passes still own two frame slots each: give them back, the host path's look-ahead wants them)
         odo = dodo = sodo = probe = None
         hodo = StereoOdometer(cam, **ODO_KW)
@@ -261,7 +265,7 @@ def bench_stereo(args, group, device, workload, K, W, light):
             pass
         ctx.synchronize()
         th = time.perf_counter()
-        for ok in hodo.run(hframes[8:]):
+        for ok in hodo.run(hframes[8 + i] for i in hwalk):
             pass
         ctx.synchronize()
         from_host_rate = nh / (time.perf_counter() - th)
@@ -387,7 +391,7 @@ def bench_stereo(args, group, device, workload, K, W, light):
             out["stage_mix_pass_pairs_per_s"] = round(mix_rate, 1)
         if from_host_rate is not None:
             out["from_host_pairs_per_s"] = round(from_host_rate, 2)    # PCIe-inclusive; never `value`
-            out["from_host_window"] = "96 pairs after 8 untimed ones (host numpy arrays through StereoOdometer.run)"
+            out["from_host_window"] = "480 pairs after 8 untimed ones (host numpy arrays through StereoOdometer.run; 96 frames walked forwards and backwards)"
         if world > 1:
             out["shard_boundaries_inexact"] = sharding.boundary_report(all_ok, R * K, world)
         # trajectory error vs the analytic ground truth (information only)
