@@ -757,3 +757,46 @@ def test_abi_misuse_returns_a_status_and_never_crashes():
                 "vo_set_roi", "vo_sgbm_last_geometry", "vo_synchronize", "vo_lookahead_depth", "vo_sgbm_last_schedule", "vo_sgbm_sweep_status",
                 "vo_slot_ready", "vo_sgbm_sweep_stats", "vo_stage_pairs_alloc"}
     assert set(last[2:]) <= harmless, set(last[2:]) - harmless
+
+
+def test_random_rigs_unrectified_input_through_update_and_run_against_the_oracle():
+    """Six random rigs (lens distortion, shifted principal point, a relative rotation and a baseline that is not along x: the
+    valid ROI then starts off the origin and the rectification maps matter), the reference's default input (unrectified pairs,
+    gray or BGR), through plain update() calls or run(depth=3): every result, skip_cause, skipped_frames and chained pose
+    against the oracle odometer working through the same maps (cvtColor -> remap -> SGBM -> crop -> ORB -> pose)."""
+    from openvo_amd import calib
+    from oracle.odometer import RefStereoCamera, RefStereoOdometer
+    rng = np.random.default_rng(71)
+    c = Corridor("T0")
+    frames = c.pairs(0, 8)
+    done = 0
+    for trial in range(6):
+        dist = np.array([rng.uniform(-0.2, 0.1), rng.uniform(-0.03, 0.05), rng.uniform(-0.002, 0.002), rng.uniform(-0.002, 0.002), rng.uniform(-0.01, 0.01)])
+        if trial % 3 == 0:
+            dist[:] = 0
+        K2 = c.K().copy()
+        K2[0, 2] += rng.uniform(-4, 4); K2[1, 2] += rng.uniform(-4, 4)
+        rect = {"R": calib.rodrigues_vec_to_mat(rng.uniform(-0.01, 0.01, 3)), "T": np.array([-c.B, rng.uniform(-0.003, 0.003), rng.uniform(-0.003, 0.003)])}
+        cam = StereoCamera(c.K(), dist, K2, dist * rng.uniform(0.8, 1.2), rect, c.sgbm_params(), (c.w, c.h), max_keypoints=200)
+        vr = cam.valid_region_left
+        if vr[2] - vr[0] < 80 or vr[3] - vr[1] < 80:
+            continue
+        rcam = RefStereoCamera(cam.Q, vr, c.sgbm_params(), maps=((cam.map_left_1, cam.map_left_2), (cam.map_right_1, cam.map_right_2)))
+        kw = dict(nfeatures=200, rigidity_threshold=float(rng.choice([0, 0.1])), outlier_threshold=float(rng.choice([0, 0.02])))
+        odo, rodo = StereoOdometer(cam, **kw), RefStereoOdometer(rcam, **kw)
+        colour, via_run = rng.random() < 0.5, rng.random() < 0.5
+        seq = [(np.ascontiguousarray(np.stack([L, L, L], -1)), np.ascontiguousarray(np.stack([R, R, R], -1))) if colour else (L, R) for L, R in frames]
+        got = []
+        if via_run:
+            for ok in odo.run(iter(seq), depth=3):
+                got.append((ok, odo.skip_cause, odo.skipped_frames, odo.c_T_w.copy()))
+        else:
+            for L, R in seq:
+                got.append((odo.update(L, R), odo.skip_cause, odo.skipped_frames, odo.c_T_w.copy()))
+        for k, (L, R) in enumerate(seq):
+            b = rodo.update(L, R)
+            a = got[k]
+            assert a[0] == b and a[1] == rodo.skip_cause and a[2] == rodo.skipped_frames, (trial, k, vr, colour, via_run)
+            assert np.allclose(a[3], rodo.c_T_w, rtol=0, atol=1e-8), (trial, k, vr)
+        done += 1
+    assert done >= 4
