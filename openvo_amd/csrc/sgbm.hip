@@ -198,8 +198,13 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
                                                         SgbmGeom g, int TY, int16_t* __restrict__ C)
 {
     constexpr int WIN = 2 * SW2 + 1, NC = XT + 2 * SW2;
-    extern __shared__ uint32_t s_ring[];  // staging of the interior strips only: [waves][12][NJ]
-    uint32_t ringv[WIN][XT];              // the vertical window's ring: registers (the row loop is unrolled by WIN, so every index is a constant)
+    // The vertical window's ring -- the horizontal sums of the last WIN rows per column and lane.  Blocks up to 5 x 5: 40 registers
+    // (the row loop is unrolled by WIN, so every ring index is a constant); the LDS the sweep then asks for is 3.3 KB per wave and
+    // the mix is sensitive to exactly that.  Larger blocks (56 .. 88 words per lane) keep the ring in LDS.
+    constexpr bool RING_REGS = WIN <= 5;
+    extern __shared__ uint32_t s_ring[];  // [waves][WIN][XT][64] when the ring lives here, then the interior strips' staging [waves][12][NJ]
+    uint32_t ringv[RING_REGS ? WIN : 1][XT];
+    uint32_t* const ring = s_ring + (size_t)(threadIdx.x >> 6) * WIN * XT * 64 + (threadIdx.x & 63);   // (LDS variant only)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int dpl = threadIdx.x;                  // disparity pair index (padded layout)
     const bool pad = 2 * dpl >= g.D;
@@ -243,7 +248,7 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
             typedef __attribute__((address_space(3))) w2 lds_w2;
             // staging layout: [parity][j][the six planes] -- a lane fetches the six planes of its position with three 8-byte reads
             // at immediate offsets; consecutive lanes are 6 words apart, which spreads every 32-lane pass over all 64 banks
-            lds_w* const stage = (lds_w*)s_ring + (size_t)wv * 12 * NJ;
+            lds_w* const stage = (lds_w*)(s_ring + (RING_REGS ? 0 : (size_t)(blockDim.x >> 6) * WIN * XT * 64)) + (size_t)wv * 12 * NJ;
             lds_w* const st_wr = stage + lane * 6;                     // + parity * NJ * 6  (+ 64 * 6 for the tail lanes)
             const lds_w* const st_rd = stage + (63 - lane) * 6;        // + ((k & 1) * NJ + (k >> 1)) * 6
             const bool tail = lane < NJ - 64;
@@ -271,7 +276,7 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
             };
             fetch(0);
             for (int rr0 = 0; rr0 < nrows; rr0 += WIN) {
-#pragma unroll
+#pragma unroll RING_REGS ? WIN : 1
             for (int slot = 0; slot < WIN; slot++) {
                 const int rr = rr0 + slot;
                 if (rr >= nrows) break;                                // (uniform)
@@ -305,9 +310,16 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
 #pragma unroll
                 for (int j = 0; j < XT; j++) {
                     if (j > 0) s = pk_sub(pk_add(s, pc[j + WIN - 1]), pc[j - 1]);
-                    if (rr >= WIN) acc[j] = pk_sub(acc[j], ringv[slot][j]);
-                    acc[j] = pk_add(acc[j], s);
-                    ringv[slot][j] = s;
+                    if constexpr (RING_REGS) {
+                        if (rr >= WIN) acc[j] = pk_sub(acc[j], ringv[slot][j]);
+                        acc[j] = pk_add(acc[j], s);
+                        ringv[slot][j] = s;
+                    } else {
+                        uint32_t* cell = ring + (size_t)(slot * XT + j) * 64;
+                        if (rr >= WIN) acc[j] = pk_sub(acc[j], *cell);
+                        acc[j] = pk_add(acc[j], s);
+                        *cell = s;
+                    }
                 }
                 if (rr >= WIN - 1) {
                     const int y = ya + rr - (WIN - 1);
@@ -326,7 +338,7 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
     }
 
     for (int rr0 = 0; rr0 < nrows; rr0 += WIN) {
-#pragma unroll
+#pragma unroll RING_REGS ? WIN : 1
     for (int slot = 0; slot < WIN; slot++) {
         const int rr = rr0 + slot;
         if (rr >= nrows) break;                                        // (uniform)
@@ -379,9 +391,16 @@ __global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restr
 #pragma unroll
         for (int j = 0; j < XT; j++) {
             if (j > 0) s = pk_sub(pk_add(s, pc[j + WIN - 1]), pc[j - 1]);
-            if (rr >= WIN) acc[j] = pk_sub(acc[j], ringv[slot][j]);   // the row leaving the window
-            acc[j] = pk_add(acc[j], s);
-            ringv[slot][j] = s;
+            if constexpr (RING_REGS) {
+                if (rr >= WIN) acc[j] = pk_sub(acc[j], ringv[slot][j]);   // the row leaving the window
+                acc[j] = pk_add(acc[j], s);
+                ringv[slot][j] = s;
+            } else {
+                uint32_t* cell = ring + (size_t)(slot * XT + j) * 64;
+                if (rr >= WIN) acc[j] = pk_sub(acc[j], *cell);
+                acc[j] = pk_add(acc[j], s);
+                *cell = s;
+            }
         }
         if (rr >= WIN - 1) {
             const int y = ya + rr - (WIN - 1);
@@ -1628,7 +1647,7 @@ static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t*
         const int nw = bx / 64;
 #define LAUNCH_SWEEP(XT, SW)                                                                                                   \
     hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(8 * div_up(div_up(g.W1, XT) * div_up(h, TY), 8)), dim3(bx),            \
-                       (size_t)nw * (12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->ws->planesL, ctx->ws->planesR, g, TY, ctx->ws->C)
+                       (size_t)nw * (((2 * SW + 1) <= 5 ? 0 : (2 * SW + 1) * XT * 64) + 12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->ws->planesL, ctx->ws->planesR, g, TY, ctx->ws->C)
         if (dbg & 4) {
         } else
         switch (g.SW2) {
