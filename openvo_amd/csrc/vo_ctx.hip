@@ -660,7 +660,7 @@ static int prefetch_pair(vo_ctx* ctx, int slot, const uint8_t* srcL, const uint8
     f.w = w; f.h = h; f.has_kp = false; f.n_kp = 0; f.kp_pending = false;
     {
         EngineScope on_engine(ctx, engine);          // ctx->stream / staging / SGBM + ORB workspaces are the engine's in here
-        const int stagger = ctx->tune_stagger >= 0 ? ctx->tune_stagger : ctx->n_engines / 2;
+        const int stagger = ctx->tune_stagger >= 0 ? ctx->tune_stagger : (7 * ctx->n_engines + 8) / 16;
         if (stagger > 0 && stagger < ctx->n_engines) {
             vo_ctx::SgbmWs& p = ctx->ws_alt[(engine - stagger + ctx->n_engines) % ctx->n_engines];
             if (p.mid_valid) (void)hipStreamWaitEvent(ctx->stream, p.mid, 0);

@@ -82,9 +82,10 @@ struct vo_ctx {
     hipStream_t la_stream[MAX_ENGINES] = {};
     int cur_engine = -1;
     // VO_STAGGER = K: a pair's early stages (cost volume, W + E) start only after those of the pair K places before it have finished
-    // (an event wait on the engine's stream; default: half the engines, 0 = off).  Keeps the pairs in flight spread over the stages
+    // (an event wait on the engine's stream; default: 7/16 of the engines, 0 = off).  Keeps the pairs in flight spread over the stages
     // -- at most K of them in the early ones -- instead of all in the same one after a cold start: +2.5 % on a 20-pair burst,
-    // +1.5 % in the steady state with 16 engines (K = 7..8; K <= 4 costs throughput, K >= 12 changes nothing).
+    // +1.5 % in the steady state with 16 engines (K = 6..8: 6 and 7 are 1 % ahead of 8 on the burst, equal in the steady state;
+    // K <= 4 costs throughput, K >= 12 changes nothing).
     int tune_stagger = -1;
     uint8_t* la_stage[MAX_ENGINES] = {};
     // One SGBM workspace: everything a disparity run writes.  The context owns one (`main_ws`: the main stream and look-ahead
