@@ -682,7 +682,7 @@ def test_hand_over_fuzz_every_way_of_passing_a_pair_equals_plain_updates(seed):
     """A 30-pair sequence (consecutive frames, now and then a textureless pair or a repeated one) is handed to one odometer in
     random chunks, each in a random way -- plain update(L, R); run() at depth 0 / 1 / 3 / 20; pairs staged in HBM and consumed in
     order; pairs submitted ahead; staged pairs abandoned half way (reset_lookahead, the look-ahead work voided) and finished with
-    plain calls; a foreign compute_3d on the same camera in between -- under a random look-ahead depth (0 / 2 / 7 / 18): every
+    plain calls; a foreign compute_3d on the same camera in between -- under a random look-ahead depth (0 / 2 / 7 / 18 / 24): every
     update()'s result, skip_cause, skipped_frames and pose are bit-identical to plain updates on a camera without look-ahead."""
     rng = np.random.default_rng(seed)
     c = Corridor("T0")
@@ -707,7 +707,7 @@ def test_hand_over_fuzz_every_way_of_passing_a_pair_equals_plain_updates(seed):
             ok = ref.update(L, R)
             want.append((ok, ref.skip_cause, ref.skipped_frames, ref.c_T_w.copy()))
         cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=200)
-        cam.lookahead = int(rng.choice([0, 2, 7, 18]))
+        cam.lookahead = int(rng.choice([0, 2, 7, 18, 24]))
         odo = StereoOdometer(cam, nfeatures=200, **kw)
         got, log, i = [], [], 0
         rec = lambda ok: got.append((ok, odo.skip_cause, odo.skipped_frames, odo.c_T_w.copy()))
