@@ -1492,7 +1492,15 @@ static int launch_diag(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int16
 {
     const bool pad = g.D != g.Dp;
     if constexpr (NP <= 4) {
-        if (ctx->tune_diag_nwc == 15)
+        // Strip width for up to 128 disparities: 7 compute waves (28 columns, 43 workgroups of 8 waves at config 2) is the shorter
+        // chain -- 0.76 ms when the launch has the GPU to itself; 15 waves (60 columns, 21 workgroups of 16 waves, one per CU) takes
+        // 1.33 ms alone but packs the sweep onto 21 CUs whose SIMDs it fills by itself, and the other pairs' W + E and cost kernels no
+        // longer share SIMDs with sweep waves (W + E in the mix 0.72 -> 0.44 ms): +3 % on the steady rate and the 20-pair window
+        // (DESIGN 4b).  So: the narrow strips for a synchronous call on the main stream (one pair, latency), the wide ones for
+        // pairs streamed through the look-ahead engines (throughput).  A workspace thereby keeps one strip width -- a change of
+        // width re-clears its boundary granules -- except the main one, which engine 0 shares with the synchronous calls.
+        const int nwc = ctx->tune_diag_nwc ? ctx->tune_diag_nwc : (ctx->cur_engine >= 0 ? 15 : 7);
+        if (nwc == 15)
             return pad ? launch_diag_k<NP, true, 15, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 15, REV, WTA>(ctx, g, in1, sout, ctl);
     }
 
