@@ -50,8 +50,8 @@ for k in kernels:
     if k.startswith(SGBM):
         tot_f += sum(fv) / npairs
         tot_w += sum(wv) / npairs
-    if k.startswith("k_sgbm_diag") and ", false, true>" in k:
-        dom = (k, int((2 * mf + mw) * 1024))
+    if k.startswith("k_sgbm_diag") and ", false, true>" in k and (dom is None or max(len(fv), len(wv)) > dom[2]):
+        dom = (k, int((2 * mf + mw) * 1024), max(len(fv), len(wv)))    # (the strip width most of the pairs ran with)
 rows.sort(key=lambda r: -(r[2] * 2 + r[3]))
 with open(os.path.join(dst, "%s_pmc_%s_summary.csv" % (tag, low)), "w") as fh:
     fh.write("kernel,dispatches,FETCH_SIZE_mean_KB_raw,WRITE_SIZE_mean_KB_raw,bytes_per_launch_corrected\n")
