@@ -53,7 +53,7 @@ class StereoOdometer:
         self._specs = {}             # (slot key a, slot key b, params) -> ticket of a pose step started ahead of time
         self._next_hint = ()         # SubmittedPairs expected by the next update() calls (set by run())
         self._ahead_counts = {}      # (slot, generation), ORB arguments -> keypoint count of a look-ahead pair already collected
-        self.pose_ahead = max(0, min(int(os.environ.get("VO_POSE_AHEAD", "6")), _native.VO_NUM_POSE_ASYNC - 1))
+        self.pose_ahead = max(0, min(int(os.environ.get("VO_POSE_AHEAD", "4")), _native.VO_NUM_POSE_ASYNC - 1))   # 4 against 6 / 5 / 3 / 2: DESIGN 4b
 
     # ------------------------------------------------------------------------------------------
     def feature_mask(self, disparity):
