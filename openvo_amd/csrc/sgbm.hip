@@ -194,7 +194,7 @@ __device__ __forceinline__ uint32_t bt_regs(uint32_t lw0, uint32_t lw1, const ui
 }
 
 template <int XT, int SW2>
-__global__ void __launch_bounds__(768) k_sgbm_cost_sweep(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR,
+__global__ void __launch_bounds__(128) k_sgbm_cost_sweep(const uint32_t* __restrict__ PL, const uint32_t* __restrict__ PR,
                                                         SgbmGeom g, int TY, int16_t* __restrict__ C)
 {
     constexpr int WIN = 2 * SW2 + 1, NC = XT + 2 * SW2;
@@ -204,8 +204,7 @@ __global__ void __launch_bounds__(768) k_sgbm_cost_sweep(const uint32_t* __restr
     constexpr bool RING_REGS = WIN <= 5;
     extern __shared__ uint32_t s_ring[];  // [waves][WIN][XT][64] when the ring lives here, then the interior strips' staging [waves][12][NJ]
     uint32_t ringv[RING_REGS ? WIN : 1][XT];
-    const int wblk = (int)threadIdx.y * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);          // this wave inside the workgroup (blockDim.y tiles side by side)
-    uint32_t* const ring = s_ring + (size_t)wblk * WIN * XT * 64 + (threadIdx.x & 63);   // (LDS variant only)
+    uint32_t* const ring = s_ring + (size_t)(threadIdx.x >> 6) * WIN * XT * 64 + (threadIdx.x & 63);   // (LDS variant only)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int dpl = threadIdx.x;                  // disparity pair index (padded layout)
     const bool pad = 2 * dpl >= g.D;
@@ -213,9 +212,8 @@ __global__ void __launch_bounds__(768) k_sgbm_cost_sweep(const uint32_t* __restr
     // contiguous band of tile rows, so that a row of the image planes is fetched into one L2 (plus the bands' halos), not eight
     // (the launch is one-dimensional: 8 x ceil(tiles / 8) workgroups)
     const int gx = (g.W1 + XT - 1) / XT, total = gx * ((g.H + TY - 1) / TY);
-    const int chunk = (total + 7) >> 3, tin = (int)(blockIdx.x >> 3) * (int)blockDim.y + (int)threadIdx.y;
-    const int tile = (int)(blockIdx.x & 7) * chunk + tin;
-    if (tin >= chunk || tile >= total) return;
+    const int chunk = (total + 7) >> 3, tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tile >= total) return;
     const int tbx = tile % gx, tby = tile / gx;
     const int xa = tbx * XT, ya = tby * TY;
     const size_t plane = (size_t)g.W * g.H;
@@ -250,7 +248,7 @@ __global__ void __launch_bounds__(768) k_sgbm_cost_sweep(const uint32_t* __restr
             typedef __attribute__((address_space(3))) w2 lds_w2;
             // staging layout: [parity][j][the six planes] -- a lane fetches the six planes of its position with three 8-byte reads
             // at immediate offsets; consecutive lanes are 6 words apart, which spreads every 32-lane pass over all 64 banks
-            lds_w* const stage = (lds_w*)(s_ring + (RING_REGS ? 0 : (size_t)(blockDim.x >> 6) * blockDim.y * WIN * XT * 64)) + (size_t)wblk * 12 * NJ;
+            lds_w* const stage = (lds_w*)(s_ring + (RING_REGS ? 0 : (size_t)(blockDim.x >> 6) * WIN * XT * 64)) + (size_t)wv * 12 * NJ;
             lds_w* const st_wr = stage + lane * 6;                     // + parity * NJ * 6  (+ 64 * 6 for the tail lanes)
             const lds_w* const st_rd = stage + (63 - lane) * 6;        // + ((k & 1) * NJ + (k >> 1)) * 6
             const bool tail = lane < NJ - 64;
@@ -1655,11 +1653,9 @@ static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t*
         const int bx = ((g.Dp / 2 + 63) / 64) * 64;
         const int TY = ctx->tune_sweep_ty;
         const int nw = bx / 64;
-static const int tpb_env = getenv("VO_SWEEP_TPB") ? atoi(getenv("VO_SWEEP_TPB")) : 1;
-        const int tpb = std::max(1, std::min(tpb_env, 768 / bx));
 #define LAUNCH_SWEEP(XT, SW)                                                                                                   \
-    hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(8 * div_up(div_up(div_up(g.W1, XT) * div_up(h, TY), 8), tpb)), dim3(bx, tpb),            \
-                       (size_t)nw * tpb * (((2 * SW + 1) <= 5 ? 0 : (2 * SW + 1) * XT * 64) + 12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->ws->planesL, ctx->ws->planesR, g, TY, ctx->ws->C)
+    hipLaunchKernelGGL((k_sgbm_cost_sweep<XT, SW>), dim3(8 * div_up(div_up(g.W1, XT) * div_up(h, TY), 8)), dim3(bx),            \
+                       (size_t)nw * (((2 * SW + 1) <= 5 ? 0 : (2 * SW + 1) * XT * 64) + 12 * (64 + (XT + 2 * SW - 1) / 2)) * 4, ctx->stream, ctx->ws->planesL, ctx->ws->planesR, g, TY, ctx->ws->C)
         if (dbg & 4) {
         } else
         switch (g.SW2) {
