@@ -327,9 +327,9 @@ def bench_stereo(args, group, device, workload, K, W, light):
             s_s, s_n, s_ach = alone(tb)
             roof.update({"achieved": round(e_ach, 2), "frac": round(e_ach / HBM_PEAK_GBS, 5), "launch_us": round(e_s * 1e6, 2), "launches": e_n,
                          "condition": "the launch with one pair at a time on a look-ahead engine (HIP events on its stream; the post kernel's "
-                                      "~10 us included).  Up to 128 disparities the streamed path runs the sweep in WIDE strips (15 compute "
-                                      "waves, one 16-wave workgroup per CU on ~21 CUs): slower as a launch than the narrow strips of a "
-                                      "synchronous call (`sync_call`), faster as a job (+3 %: the other pairs' kernels no longer share SIMDs "
+                                      "~10 us included).  Up to 128 disparities the streamed path runs the sweep in WIDER strips (11 compute "
+                                      "waves, one 12-wave workgroup per CU on ~28 CUs): slower as a launch than the narrow strips of a "
+                                      "synchronous call (`sync_call`), faster as a job (+8 %: the other pairs' kernels no longer share SIMDs "
                                       "with sweep waves; DESIGN 4b).  The kernel is a latency chain by design; the job's rate is in `aggregate`"})
             roof["sync_call"] = {"launch_us": round(s_s * 1e6, 2), "launches": s_n, "achieved": round(s_ach, 2), "frac": round(s_ach / HBM_PEAK_GBS, 5),
                                  "note": "the same sweep as a synchronous call runs it (look-ahead off, one pair at a time on the main stream): narrow "

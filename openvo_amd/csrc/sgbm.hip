@@ -1492,16 +1492,29 @@ static int launch_diag(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int16
 {
     const bool pad = g.D != g.Dp;
     if constexpr (NP <= 4) {
-        // Strip width for up to 128 disparities: 7 compute waves (28 columns, 43 workgroups of 8 waves at config 2) is the shorter
-        // chain -- 0.76 ms when the launch has the GPU to itself; 15 waves (60 columns, 21 workgroups of 16 waves, one per CU) takes
-        // 1.33 ms alone but packs the sweep onto 21 CUs whose SIMDs it fills by itself, and the other pairs' W + E and cost kernels no
-        // longer share SIMDs with sweep waves (W + E in the mix 0.72 -> 0.44 ms): +3 % on the steady rate and the 20-pair window
-        // (DESIGN 4b).  So: the narrow strips for a synchronous call on the main stream (one pair, latency), the wide ones for
+        // Strip width for up to 128 disparities.  7 compute waves (28 columns, 43 workgroups of 8 waves at config 2) is the shortest
+        // chain: 0.76 ms when the launch has the GPU to itself.  Wider strips take longer alone (11 waves: 1.02 ms, 15: 1.33 ms) but
+        // pack the sweep: a workgroup of 12 or 16 waves with 94 .. 157 KB of LDS has its CU to itself and fills its SIMDs with sweep
+        // waves, so the other pairs' W + E and cost kernels get CUs of their own instead of sharing SIMDs with half-idle sweep
+        // waves.  Steady rate with 7 / 9 / 10 / 11 / 12 / 13 / 15 waves: 2292 / 2381 / 2466 / 2479 / 2436 / 2345 / 2366 pairs/s
+        // (DESIGN 4b).  So: the narrow strips for a synchronous call on the main stream (one pair, latency), 11-wave strips for
         // pairs streamed through the look-ahead engines (throughput).  A workspace thereby keeps one strip width -- a change of
         // width re-clears its boundary granules -- except the main one, which engine 0 shares with the synchronous calls.
-        const int nwc = ctx->tune_diag_nwc ? ctx->tune_diag_nwc : (ctx->cur_engine >= 0 ? 15 : 7);
+        const int nwc = ctx->tune_diag_nwc ? ctx->tune_diag_nwc : (ctx->cur_engine >= 0 ? 11 : 7);
         if (nwc == 15)
             return pad ? launch_diag_k<NP, true, 15, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 15, REV, WTA>(ctx, g, in1, sout, ctl);
+        if (nwc == 11)
+            return pad ? launch_diag_k<NP, true, 11, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 11, REV, WTA>(ctx, g, in1, sout, ctl);
+#ifdef VO_DIAG_EXTRA_WIDTHS
+        if (nwc == 9)
+            return pad ? launch_diag_k<NP, true, 9, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 9, REV, WTA>(ctx, g, in1, sout, ctl);
+        if (nwc == 10)
+            return pad ? launch_diag_k<NP, true, 10, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 10, REV, WTA>(ctx, g, in1, sout, ctl);
+        if (nwc == 12)
+            return pad ? launch_diag_k<NP, true, 12, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 12, REV, WTA>(ctx, g, in1, sout, ctl);
+        if (nwc == 13)
+            return pad ? launch_diag_k<NP, true, 13, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 13, REV, WTA>(ctx, g, in1, sout, ctl);
+#endif
     }
 
     return pad ? launch_diag_k<NP, true, 7, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 7, REV, WTA>(ctx, g, in1, sout, ctl);

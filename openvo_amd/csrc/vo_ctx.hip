@@ -214,7 +214,7 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     if (const char* e27 = getenv("VO_DIAG_WGS")) ctx->tune_diag_wgs = atoi(e27);
     if (const char* e26 = getenv("VO_DIAG_DEBUG")) ctx->tune_diag_dbg = atoi(e26);
     if (const char* e27 = getenv("VO_STAGGER")) ctx->tune_stagger = atoi(e27);
-    if (const char* e25 = getenv("VO_DIAG_WAVES")) ctx->tune_diag_nwc = atoi(e25) == 15 ? 15 : (atoi(e25) == 7 ? 7 : 0);
+    if (const char* e25 = getenv("VO_DIAG_WAVES")) ctx->tune_diag_nwc = (atoi(e25) >= 7 && atoi(e25) <= 15) ? atoi(e25) : 0;   // (7, 11, 15 are built; others fall back to 7 unless VO_DIAG_EXTRA_WIDTHS)
 #ifdef VO_TEST_HOOKS
     if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);   // test-only build (libvo355_hooks.so)
     if (const char* e11 = getenv("VO_FAULT_SWEEP")) ctx->fault_sweep = atoi(e11);

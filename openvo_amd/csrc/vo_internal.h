@@ -155,7 +155,7 @@ struct vo_ctx {
     int sw_ctl_words = 0;
     int tune_diag_wgs = 0;         // VO_DIAG_WGS (development): workgroups of one diagonal sweep (0 = one image row's worth of strips + 2)
     int tune_diag_dbg = 0;         // VO_DIAG_DEBUG (development): bit 0 / 1 = strips import / export nothing, 4 / 8 / 16 / 32 = skip the cost / W+E / diagonal / post stage
-    int tune_diag_nwc = 0;         // VO_DIAG_WAVES: compute waves per strip workgroup (7 or 15) for Dp <= 128; 0 = 7 for synchronous calls, 15 on the look-ahead engines (launch_diag)
+    int tune_diag_nwc = 0;         // VO_DIAG_WAVES: compute waves per strip workgroup (7, 11 or 15) for Dp <= 128; 0 = 7 for synchronous calls, 11 on the look-ahead engines (launch_diag)
     int64_t last_cells = 0;
     int last_paths = 0;
     int last_schedule = 0;         // VO_SCHED_* of the latest run (vo_sgbm_last_schedule)

@@ -159,6 +159,9 @@ SIZES = [  # name, mode, numDisparities, (w, h) crop or None, compute waves per 
     ("C1", 0, 64, (633, 471), 7, "ragged"), ("C1", 1, 64, (633, 471), 7, "ragged"),  # width - D = 569: W + E by k_sgbm_pair
     ("C1", 0, 64, (134, 59), 7, "ragged"), ("C1", 1, 112, (200, 59), 7, "diag"),     # lines shorter than two segments; fewer rows than a strip is wide
     ("C1", 0, 64, (79, 64), 15, "ragged"),                                        # width - D = 15 < one segment
+    # 11 compute waves per strip: the width the look-ahead engines use by default (launch_diag)
+    ("T0", 0, 48, None, 11, "diag"), ("C1", 0, 64, None, 11, "diag"), ("C1", 1, 64, None, 11, "diag"), ("C1", 1, 112, (632, 471), 11, "diag"),
+    ("C1", 0, 32, None, 11, "diag"), ("C1", 0, 96, None, 11, "diag"), ("C1", 0, 64, (79, 64), 11, "ragged"), ("C1", 1, 112, (200, 59), 11, "diag"),
 ]
 
 
