@@ -16,6 +16,13 @@
 #define EDGE VO_ORB_EDGE
 #define HALF_PATCH VO_ORB_HALF_PATCH
 #define FAST_T 20
+#ifndef ORB_FAST_GRID_CAP
+#define ORB_FAST_GRID_CAP 2048   // workgroups of k_orb_fast_nms (they walk the tiles of all levels)
+#endif
+#ifndef ORB_CONE_W
+#define ORB_CONE_W 64            // level-0 footprint of one pyramid cone (k_orb_pyramid)
+#define ORB_CONE_H 48
+#endif
 #ifndef ORB_FAST_TH
 #define ORB_FAST_TH 32
 #endif
@@ -113,8 +120,8 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h)
     int pyr_nbx, pyr_nby, pyr_buf[2] = { 0, 0 }, pyr_tab = 0;
     {
         const LevelDev& top = L.l[NL - 1];
-        pyr_nbx = std::max(1, std::min({ div_up(w, 64), top.w / 8, 48 }));
-        pyr_nby = std::max(1, std::min({ div_up(h, 48), top.h / 8, 48 }));
+        pyr_nbx = std::max(1, std::min({ div_up(w, ORB_CONE_W), top.w / 8, 48 }));
+        pyr_nby = std::max(1, std::min({ div_up(h, ORB_CONE_H), top.h / 8, 48 }));
         auto intervals = [&](int nb, bool xaxis, std::vector<int32_t>& out) {     // out[l][b][2]
             out.assign((size_t)NL * nb * 2, 0);
             for (int b = 0; b < nb; b++) {
@@ -1048,7 +1055,7 @@ static int orb_enqueue(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img
     int fast_tiles = 0;
     for (int l = 0; l < NL; l++)
         if (Lh->l[l].w > 2 * EDGE && Lh->l[l].h > 2 * EDGE) fast_tiles += div_up(Lh->l[l].w - 2 * EDGE, 64) * div_up(Lh->l[l].h - 2 * EDGE, ORB_FAST_TH);
-    hipLaunchKernelGGL(k_orb_fast_nms, dim3(std::max(1, std::min(fast_tiles, 2048))), dim3(256), 0, ctx->stream, dL,
+    hipLaunchKernelGGL(k_orb_fast_nms, dim3(std::max(1, std::min(fast_tiles, ORB_FAST_GRID_CAP))), dim3(256), 0, ctx->stream, dL,
                        ctx->orbws->pyr_img, ctx->orbws->pyr_mask, with_mask, ctx->orbws->cand_pos, ctx->orbws->cand_resp, ctx->orbws->counters);
     // after the select, cand_* hold the per-level final lists; candB_* are scratch
     if (nfeatures <= 2000) {
