@@ -146,6 +146,21 @@ def orb_level_size(w, h, level):
     return lw.value, lh.value
 
 
+class orb_variant:
+    """`with orb_variant(flags):` runs the ORB restatement with the recalled-not-read details of orb.cpp
+    switched (bit 0: level size cvRound(cols / scale); bit 1: cosf / sinf) -- only to MEASURE what they weigh."""
+
+    def __init__(self, flags):
+        self.flags = int(flags)
+
+    def __enter__(self):
+        self.old = lib().vo_ref_orb_get_variant()
+        lib().vo_ref_orb_set_variant(self.flags)
+
+    def __exit__(self, *exc):
+        lib().vo_ref_orb_set_variant(self.old)
+
+
 def resize_linear_exact(src, dw, dh):
     src = _c(src, np.uint8)
     out = np.empty((dh, dw), np.uint8)

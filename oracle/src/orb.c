@@ -34,11 +34,25 @@ static int cv_round_d(double v) { return (int)nearbyint(v); }
 
 static float level_scale(int level) { return (float)pow((double)1.2f, (double)level); }
 
+/* Two details of orb.cpp are recalled, not read (no OpenCV source or binary on this box); both are
+ * switchable so that their weight can be MEASURED (tests/test_orb_variants.py, tests/orb_variants.py):
+ *   bit 0: level size as cvRound(cols / scale) instead of cvRound(cols * (1.f / scale))
+ *   bit 1: cosf / sinf (what `cos(float)` resolves to under libstdc++) instead of (float)cos((double)) */
+static int g_variant = 0;
+void vo_ref_orb_set_variant(int flags) { g_variant = flags; }
+int vo_ref_orb_get_variant(void) { return g_variant; }
+
 int vo_ref_orb_level_size(int w, int h, int level, int* lw, int* lh)
 {
-    float inv = 1.0f / level_scale(level);
-    *lw = cv_round_f((float)w * inv);
-    *lh = cv_round_f((float)h * inv);
+    float scale = level_scale(level);
+    if (g_variant & 1) {
+        *lw = cv_round_f((float)w / scale);
+        *lh = cv_round_f((float)h / scale);
+    } else {
+        float inv = 1.0f / scale;
+        *lw = cv_round_f((float)w * inv);
+        *lh = cv_round_f((float)h * inv);
+    }
     return 0;
 }
 
@@ -306,7 +320,9 @@ int vo_ref_orb_detect_and_compute(const uint8_t* img, int w, int h, int stride,
             /* descriptor */
             float iscale = 1.f / lscale[l];
             float ar = angle * (float)(3.1415926535897932384626433832795 / 180.f);
-            float ca = (float)cos((double)ar), sa = (float)sin((double)ar);
+            float ca, sa;
+            if (g_variant & 2) { ca = cosf(ar); sa = sinf(ar); }
+            else { ca = (float)cos((double)ar); sa = (float)sin((double)ar); }
             int cx = cv_round_f(px * iscale), cy = cv_round_f(py * iscale);
             const uint8_t* bc = B + (size_t)cy * W + cx;
             uint8_t* dsc = desc + (size_t)total * 32;

@@ -75,6 +75,10 @@ void vo_ref_fast_score_map(const uint8_t* img, int w, int h, int stride, int thr
 void vo_ref_resize_linear_exact(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst,
                                 int dw, int dh, int dstride);
 int vo_ref_orb_level_size(int w, int h, int level, int* lw, int* lh);
+/* the two recalled-not-read details of orb.cpp as switches (0 = what the oracle and the HIP path use):
+ * bit 0 level size cvRound(cols / scale); bit 1 cosf / sinf for the descriptor rotation */
+void vo_ref_orb_set_variant(int flags);
+int vo_ref_orb_get_variant(void);
 
 /* ---- matcher (reference stereo_odometer.py:163-164): core/src/batch_distance.cpp ---- */
 void vo_ref_bf_knn2_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx,
