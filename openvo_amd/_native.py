@@ -70,6 +70,16 @@ def _image_pair(left, right):
     return out[0], out[1], (3 if out[0].ndim == 3 else 1)
 
 
+def _image(img):
+    """(img, channels) for ONE image under the same rule as _image_pair (monocular entry points)."""
+    a = np.asarray(img)
+    if a.ndim == 3 and a.shape[2] == 1:
+        a = a[:, :, 0]
+    if a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+        raise ValueError("an image must be HxW or HxWx3 (got shape %s)" % (a.shape,))
+    return _c(a, np.uint8), (3 if a.ndim == 3 else 1)
+
+
 def build_native(force=False):
     """Compile openvo_amd/csrc/*.hip for gfx950 into openvo_amd/libvo355.so."""
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h", ".inc"))]
@@ -523,8 +533,7 @@ class Context:
 
     def upload_mono(self, slot, img):
         """One image into a slot (monocular front end)."""
-        ch = 3 if img.ndim == 3 else 1
-        img = _c(img, np.uint8)
+        img, ch = _image(img)      # HxWx4 / HxWx2 are refused before native code would read w*h*3 bytes from them
         h, w = img.shape[:2]
         self._ck(self._lib.vo_upload_mono(self._h, slot, _p(img), w, h, ch))
         return w, h

@@ -207,3 +207,31 @@ def test_image_arguments_are_validated_before_a_pointer_reaches_native_code():
         _image_pair(g, np.zeros((6, 9), np.uint8))
     with pytest.raises(ValueError):
         _image_pair(g, np.zeros((6, 8, 3), np.uint8))
+
+
+def test_the_monocular_upload_validates_its_image_the_same_way():
+    """Context.upload_mono took the channel count from ndim alone: an HxWx4 (or HxWx2) array made native code read w*h*3 bytes
+    from a buffer of another size.  The check runs before the library is touched (a Context without a handle suffices)."""
+    from openvo_amd._native import Context, _image
+
+    class _Lib:
+        def __init__(self):
+            self.calls = []
+
+        def vo_upload_mono(self, h, slot, ptr, w, hh, ch):
+            self.calls.append((slot, w, hh, ch))
+            return 0
+
+    ctx = Context.__new__(Context)
+    ctx._lib, ctx._h = _Lib(), None
+    ctx._ck = lambda rc: rc
+    assert ctx.upload_mono(0, np.zeros((6, 8), np.uint8)) == (8, 6)
+    assert ctx.upload_mono(1, np.zeros((6, 8, 1), np.uint8)) == (8, 6)
+    assert ctx.upload_mono(2, np.zeros((6, 8, 3), np.float32)) == (8, 6)
+    assert ctx._lib.calls == [(0, 8, 6, 1), (1, 8, 6, 1), (2, 8, 6, 3)]
+    for bad in (np.zeros((6, 8, 4), np.uint8), np.zeros((6, 8, 2), np.uint8), np.zeros(7, np.uint8), np.zeros((1, 2, 3, 3), np.uint8)):
+        with pytest.raises(ValueError):
+            ctx.upload_mono(0, bad)
+    assert len(ctx._lib.calls) == 3
+    img, ch = _image(np.zeros((6, 16, 3), np.uint8)[:, ::2])
+    assert ch == 3 and img.flags["C_CONTIGUOUS"] and img.shape == (6, 8, 3)
