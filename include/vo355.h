@@ -46,6 +46,12 @@ void vo_destroy(vo_ctx* ctx);
 const char* vo_last_error(const vo_ctx* ctx);
 int vo_device_name(const vo_ctx* ctx, char* buf, int buflen);
 int vo_synchronize(vo_ctx* ctx);
+/* How many look-ahead engines the context may use (each owns a HIP stream and a full SGBM + ORB workspace, allocated on its
+ * first use: ~0.95 GB at 1280x720 / D = 128).  n <= 0 only asks.  Returns the count in effect (clamped to 1 .. 24 and to what
+ * fits 40 % of the device's free memory), or a negative status.  May be called at any time; engines already created above a
+ * lowered count keep their memory until vo_destroy but receive no further pairs.  The reference has no counterpart (cv2 keeps
+ * one StereoSGBM object per StereoCamera, stereo_camera.py:23): this bounds the footprint of the replacement. */
+int vo_set_engines(vo_ctx* ctx, int n);
 
 /* one-off configuration (stereo_camera.py:16-27) ------------------------------------ */
 /* map_left_1/2, map_right_1/2 of cv2.initUndistortRectifyMap(..., CV_16SC2)  [stereo_camera.py:19-22] */

@@ -22,7 +22,7 @@ T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "
 
 # every symbol include/vo355.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "vo_create", "vo_destroy", "vo_last_error", "vo_device_name", "vo_synchronize",
+    "vo_create", "vo_destroy", "vo_last_error", "vo_device_name", "vo_synchronize", "vo_set_engines",
     "vo_set_rectify_maps", "vo_set_sgbm", "vo_set_Q", "vo_set_roi", "vo_upload_pair",
     "vo_stage_pairs_alloc", "vo_stage_pair", "vo_load_staged_pair", "vo_prefetch_staged_pair",
     "vo_set_lookahead_orb", "vo_prefetch_pair",
@@ -111,6 +111,7 @@ def lib():
         L.vo_destroy.argtypes = [ctypes.c_void_p]
         vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
         L.vo_create.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(vp)]
+        L.vo_set_engines.argtypes = [vp, ci]
         L.vo_device_name.argtypes = [vp, ctypes.c_char_p, ci]
         L.vo_synchronize.argtypes = [vp]
         L.vo_set_rectify_maps.argtypes = [vp, ci, vp, vp, ci, ci]
@@ -194,16 +195,30 @@ def _c(a, dt):
 class Context:
     """One device context (one HIP stream).  Not thread-safe: one per thread / per GPU."""
 
-    def __init__(self, device=0, max_w=1280, max_h=720, max_disp=128, max_kp=2000):
+    def __init__(self, device=0, max_w=1280, max_h=720, max_disp=128, max_kp=2000, engines=None):
+        """engines: how many look-ahead engines the context may use (None: the library's default of 16, or VO_ENGINES) -- each
+        owns a stream and, from its first use on, a full SGBM + ORB workspace (0.95 GB at 1280x720 / D = 128)."""
         self._lib = lib()
         h = ctypes.c_void_p()
         rc = self._lib.vo_create(int(device), int(max_w), int(max_h), int(max_disp), int(max_kp), ctypes.byref(h))
         if rc != 0:
             raise VoError(rc, (self._lib.vo_last_error(None) or b"").decode())
         self._h = h
+        if engines is not None:
+            if int(engines) < 1:
+                self.close()
+                raise ValueError("engines must be >= 1")
+            self.set_engines(engines)
         self._la_orb = None
         self.device, self.max_w, self.max_h, self.max_disp, self.max_kp = device, max_w, max_h, max_disp, max_kp
         self.kp_cap = max_kp * 2 + 1024
+
+    def set_engines(self, n=0):
+        """-> the number of look-ahead engines in effect (n <= 0 only asks)."""
+        rc = self._lib.vo_set_engines(self._h, int(n))
+        if rc < 0:
+            raise VoError(rc, "vo_set_engines")
+        return rc
 
     def close(self):
         if getattr(self, "_h", None):

@@ -208,7 +208,8 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
         double budget = 96e9;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = 0.4 * (double)free_b;
         const int fit = (int)(budget / per_engine);
-        if (ctx->n_engines > fit) ctx->n_engines = fit < 2 ? 2 : fit;
+        ctx->engines_fit = fit < 2 ? 2 : fit;
+        if (ctx->n_engines > ctx->engines_fit) ctx->n_engines = ctx->engines_fit;
     }
     if (const char* e9 = getenv("VO_POSE_STREAMS")) { int v = atoi(e9); if (v >= 1 && v <= vo_ctx::N_POSE_STREAMS) ctx->n_pose_streams = v; }
     if (const char* e27 = getenv("VO_DIAG_WGS")) ctx->tune_diag_wgs = atoi(e27);
@@ -273,6 +274,18 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+extern "C" int vo_set_engines(vo_ctx* ctx, int n)
+{
+    if (!ctx) return VO_E_ARG;
+    if (n > 0) {
+        if (n > vo_ctx::MAX_ENGINES) n = vo_ctx::MAX_ENGINES;
+        if (n > ctx->engines_fit) n = ctx->engines_fit;
+        ctx->n_engines = n;
+        ctx->next_engine %= n;          // (the stagger wait and the monocular span index modulo n_engines: nothing else remembers one)
+    }
+    return ctx->n_engines;
 }
 
 extern "C" int vo_device_name(const vo_ctx* ctx, char* buf, int buflen)

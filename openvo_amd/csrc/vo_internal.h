@@ -122,6 +122,7 @@ struct vo_ctx {
     int* d_sweep_errs = nullptr;     // device counter: SGBM runs of this context whose sweep gave up a hand-off (vo_sgbm_sweep_status)
     int tune_spin_limit = 1 << 22;   // polls before a wait inside the diagonal sweep is declared dead
     int fault_sweep = 0;             // VO_FAULT_SWEEP=n (VO_TEST_HOOKS builds only): the n-th diagonal sweep exports nothing and gives up after a few polls
+    int engines_fit = 24;            // what 40 % of the device's free memory held at vo_create (vo_set_engines clamps to it)
     int n_engines = 16;              // VO_ENGINES (needs GPU_MAX_HW_QUEUES >= engines + 4: streams sharing a hardware queue serialise)
     int next_engine = 0;
     int max_w = 0, max_h = 0, max_disp = 0, max_kp = 0, kp_cap = 0;

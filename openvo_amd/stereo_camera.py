@@ -116,9 +116,12 @@ class StereoCamera:
         _save_plain(sgbm_file, {k: int(sgbm_params[k]) for k in StereoCamera.SGBM_KEYS})
 
     def __init__(self, K_left, dist_left, K_right, dist_right, rect_params, sgbm_params, img_size,
-                 device=0, max_keypoints=2000, context=None):
+                 device=0, max_keypoints=2000, context=None, engines=None, lookahead=None):
         """img_size = (width, height) as cv2 takes it.  Extra keyword arguments (not in the reference):
-        device = HIP device index, max_keypoints = largest nfeatures an odometer may ask for."""
+        device = HIP device index, max_keypoints = largest nfeatures an odometer may ask for, engines = how many look-ahead
+        engines the context may create (default 16; each holds a full SGBM workspace from its first use on -- 0.95 GB at
+        1280x720 / D = 128 -- so `engines=4` bounds the library at ~4 GB beside the frame slots), lookahead = how many staged
+        pairs run ahead of update() (default 24, never more than engines + 8 when engines is given)."""
         w, h = int(img_size[0]), int(img_size[1])
         (R1, R2, P1, P2, self.Q, self.valid_region_left,
          self.valid_region_right) = calib.stereo_rectify(K_left, dist_left, K_right, dist_right, (w, h),
@@ -128,7 +131,9 @@ class StereoCamera:
         self.img_size = (w, h)
         D = int(sgbm_params["numDisparities"])
         self._ctx = context or _native.Context(device, max(w, 64), max(h, 64), max(16, ((D + 15) // 16) * 16),
-                                               int(max_keypoints))
+                                               int(max_keypoints), engines=engines)
+        if context is not None and engines is not None:
+            context.set_engines(engines)
         self._ctx.set_rectify_maps(0, self.map_left_1, self.map_left_2)
         self._ctx.set_rectify_maps(1, self.map_right_1, self.map_right_2)
         self._ctx.set_Q(self.Q)
@@ -144,6 +149,10 @@ class StereoCamera:
         # from-host path short of slots; env VO_LOOKAHEAD overrides).  24 against 18, five alternating runs each: steady rate
         # 2254 +- 2 against 2208 +- 3 pairs/s, 20-pair window 1767 +- 9 against 1750 +- 7
         self.lookahead = int(os.environ.get("VO_LOOKAHEAD", "24"))
+        if lookahead is not None:
+            self.lookahead = max(0, min(int(lookahead), _native.VO_NUM_SLOTS - 3))
+        elif engines is not None and "VO_LOOKAHEAD" not in os.environ:
+            self.lookahead = min(self.lookahead, self._ctx.set_engines(0) + 8)
         self._lookahead = []         # [((index, preprocessed), slot, (w, h))] of the pairs in flight
         self._n_staged = 0
         self.lookahead_stop = None   # staged pairs at or beyond this index are never started ahead (None: up to the last staged pair)

@@ -617,6 +617,42 @@ def test_scheduling_knobs_change_nothing_but_the_order(env, monkeypatch):
         assert a == b and np.array_equal(Ta, Tb)
 
 
+def test_engine_count_as_a_constructor_argument_bounds_the_footprint_and_changes_no_result():
+    """StereoCamera(..., engines=2): the context creates at most two look-ahead workspaces (device memory in use stays below
+    the default's), the look-ahead follows, lowering it later is allowed, and flags and poses stay bit-identical."""
+    c = Corridor("C1")
+    frames = c.pairs(0, 12)
+    kw = dict(preprocessed_frames=True, rigidity_threshold=0.1, outlier_threshold=0.02)
+
+    def chain(**cam_kw):
+        cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=500, **cam_kw)
+        odo = StereoOdometer(cam, **kw)
+        staged = cam.stage_pairs(frames)
+        out = []
+        for k, s in enumerate(staged):
+            if k == 6 and cam_kw.get("engines") == 3:
+                assert cam._ctx.set_engines(1) == 1                      # lowered mid-stream: later pairs all go to engine 0
+            out.append((odo.update(s, None), odo.c_T_w.copy()))
+        used = cam._ctx.mem_used() if hasattr(cam._ctx, "mem_used") else None
+        n = cam._ctx.set_engines(0)
+        la = cam.lookahead
+        cam._ctx.close()
+        return out, n, la, used
+
+    want, n_def, la_def, _ = chain()
+    assert n_def >= 2 and la_def >= 2
+    for eng in (2, 3):
+        got, n, la, _ = chain(engines=eng)
+        assert n == (1 if eng == 3 else 2) and la <= eng + 8
+        for (a, Ta), (b, Tb) in zip(got, want):
+            assert a == b and np.array_equal(Ta, Tb)
+    with pytest.raises(ValueError):
+        chain(engines=0)
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), engines=1000, lookahead=99)
+    assert 2 <= cam._ctx.set_engines(0) <= 24 and cam.lookahead == _native.VO_NUM_SLOTS - 3
+    cam._ctx.close()
+
+
 def test_lookahead_depth_counts_what_is_really_in_flight():
     """vo_lookahead_depth: pairs submitted ahead and neither consumed nor dropped.  A reset of the look-ahead (and a fresh
     stage_pairs) must bring it back to zero although the dropped slots' work may still be running."""
