@@ -27,10 +27,16 @@ def _queue_budget():
     if share < 2:
         _os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
         return
-    hwq = max(6, 24 // share)
+    # never more than the ~24 queues in total: 8 ranks rehearsed on one GPU get 3 each (main stream, one pose stream, one
+    # engine); beyond 8 sharers the sum exceeds the budget whatever each takes, and the regime is the time-sliced one again
+    hwq = max(3, 24 // share)
     _os.environ.setdefault("GPU_MAX_HW_QUEUES", str(hwq))
+    if share > 8:
+        import warnings as _w
+        _w.warn("VO_SHARE_GPU=%d: more than 8 processes on one GPU cannot each keep a hardware queue per stream; expect "
+                "time-sliced queues (slow sweeps, SweepTimeout)" % share, RuntimeWarning)
     pose = 2 if hwq >= 10 else 1
-    engines = max(2, hwq - 2 - pose)   # one queue for the main stream, one spare
+    engines = max(1, hwq - (2 if hwq >= 6 else 1) - pose)   # one queue for the main stream (+ one spare where there is room)
     _os.environ.setdefault("VO_POSE_STREAMS", str(pose))
     _os.environ.setdefault("VO_ENGINES", str(engines))
     _os.environ.setdefault("VO_LOOKAHEAD", str(engines + 2))

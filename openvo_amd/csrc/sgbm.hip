@@ -1642,6 +1642,11 @@ static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t*
     g.invalid16 = (e.minD - 1) * 16;
     const int n = w * h;
     if (g.W1 <= 0) {
+        // (in-place ingest: the kernel that would have left the slot's copy of the pair behind does not run on this path)
+        if (srcL) {
+            VO_HIP(ctx, hipMemcpyAsync(f.left, srcL, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+            VO_HIP(ctx, hipMemcpyAsync(f.right, srcR, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        }
         std::vector<int16_t> inv((size_t)n, (int16_t)g.invalid16);  // every pixel invalid
         VO_HIP(ctx, hipMemcpyAsync(d_disp, inv.data(), (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream));
         VO_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -251,6 +251,13 @@ class StereoCamera:
         self._slot_owner[slot] = None
         self._ctx.lookahead_drop(slot)
 
+    def release_submitted(self, submitted):
+        """Give back the slot of a SubmittedPair that will never be passed to compute_3d / update (idempotent)."""
+        if isinstance(submitted, SubmittedPair):
+            if submitted.slot is not None and self._slot_owner[submitted.slot] is _RESERVED:
+                self._drop(submitted.slot)
+            submitted.slot, submitted.images = None, None
+
     def slot_key(self, slot):
         """(slot, generation): identifies the pair a slot holds right now."""
         return (slot, self._slot_gen[slot])

@@ -142,9 +142,13 @@ class StereoOdometer:
                 and not any(n in self.__dict__ for n in self._SEAMS))
 
     def _drop_specs(self, keep=()):
+        """Collect and discard pose steps begun ahead.  A step's own error (e.g. VO_E_SWEEP on a pair it read) is discarded with
+        it: it belongs to a result nobody asked for, and that pair's own update() reports what is wrong with it."""
         for key in [k for k in self._specs if k not in keep]:
             try:
                 self._ctx.pose_pair_end(self._specs[key])
+            except _native.VoError:
+                pass
             finally:
                 del self._specs[key]
 
@@ -202,7 +206,7 @@ class StereoOdometer:
                 except VoError:
                     break                    # nothing started: update() computes the step when it gets there
 
-    def run(self, pairs, depth=None):
+    def run(self, pairs, depth=None, on_sweep_timeout="raise"):
         """Feed an iterable of host (left, right) pairs through update(), keeping up to `depth` pairs
         submitted ahead so their upload and disparity overlap the tracking of the current pair.  Yields
         update()'s result per pair, in order.  Not in the reference (whose update() takes one host pair per call,
@@ -212,8 +216,17 @@ class StereoOdometer:
         pair ahead of the pair being submitted: it overlaps this thread's kernel launches and waits, this thread never touches
         image bytes, and no second Python thread competes for the interpreter lock.  The caller may refill the arrays it
         yielded as soon as it is asked for the next pair (a copy is waited for before the iterator is advanced).  Pairs whose
-        two images differ in channel count go through StereoCamera.submit() instead."""
+        two images differ in channel count go through StereoCamera.submit() instead.
+
+        A pair whose disparity is undefined (update() raises SweepTimeout, see there): with on_sweep_timeout="raise" (default)
+        the exception leaves the generator, which ends -- the failed pair and the pairs already taken from `pairs` but not yet
+        yielded (at most depth + 2) are lost to this run, every frame slot they held is given back, the odometer's state is
+        that of the last yielded result, and a new run() may follow at once; with "skip" the generator yields None for that
+        pair (neither accepted nor counted as skipped: the odometer's state is untouched) and carries on with the next one.
+        Either way no slot stays reserved when the generator ends, however it ends (exhausted, closed, or by an exception)."""
         from collections import deque
+        if on_sweep_timeout not in ("raise", "skip"):
+            raise ValueError("on_sweep_timeout must be 'raise' or 'skip'")
         cam, ctx = self.stereo, self.stereo._ctx
         depth = int(cam.lookahead if depth is None else depth)
         nbuf = _native.VO_NUM_HOST_STAGE
@@ -261,12 +274,29 @@ class StereoOdometer:
                 head = queue.popleft()
                 self._next_hint = tuple(queue)[:self.pose_ahead]
                 try:
-                    yield self.update(head, None)
+                    try:
+                        res = self.update(head, None)
+                    except _native.SweepTimeout:
+                        if on_sweep_timeout != "skip":
+                            raise
+                        res = None
+                    yield res
                 finally:
                     self._next_hint = ()
         finally:
             if state["inflight"] is not None:                            # a copy begun and never submitted: its sources may go away now
                 ctx.host_stage_wait(state["inflight"])
+            # pairs submitted ahead that nobody will consume (the generator was closed early, or an exception ended it): their
+            # slots are marked reserved and only a consumer ever un-marks one -- give them back, or up to depth + 1 of the 28
+            # slots stay stranded and later submissions fall back to synchronous processing.  Pose steps begun ahead on them
+            # are collected first (they read the slots); whatever still runs is ordered before a slot's next use.
+            if any(sp.slot is not None for sp in queue):
+                try:
+                    self._drop_specs()
+                finally:
+                    for sp in queue:
+                        cam.release_submitted(sp)
+                    queue.clear()
 
     _SEAMS = ("point_clouds", "point_cloud_transform", "rigid_body_filter", "bilinear_interpolate_pixels",
               "_estimate", "_gate")

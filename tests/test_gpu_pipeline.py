@@ -517,6 +517,41 @@ def _sweep_timeout_body():
     assert cam2._ctx.sgbm_sweep_status() == 1
     for (a, Ta), (b, Tb) in zip(got2, want):
         assert a == b and np.array_equal(Ta, Tb)
+
+    # (c) the same through run() (host pairs submitted ahead): by default the exception ends the generator and EVERY slot the
+    # pairs submitted ahead held is given back (they used to stay reserved: one timeout stranded up to 25 of the 28 slots);
+    # a second run() on the same camera is bit-exact.  With on_sweep_timeout="skip" the generator yields None and carries on.
+    from openvo_amd.stereo_camera import _RESERVED
+    os.environ["VO_FAULT_SWEEP"] = "4"
+    c4, cam4 = _rig("C1", max_keypoints=500)
+    del os.environ["VO_FAULT_SWEEP"]
+    odo4 = StereoOdometer(cam4, **kw)
+    got4 = []
+    with pytest.raises(_native.SweepTimeout):
+        for ok in odo4.run(iter(frames)):
+            got4.append((ok, odo4.c_T_w.copy()))
+    assert len(got4) == 3                                        # pairs 0..2 yielded, pair 3 raised
+    assert not any(o is _RESERVED for o in cam4._slot_owner), "slots of pairs submitted ahead stayed reserved"
+    assert cam4._ctx.lookahead_depth() == 0
+    for (a, Ta), (b, Tb) in zip(got4, want):
+        assert a == b and np.array_equal(Ta, Tb)
+    odo4b = StereoOdometer(cam4, **kw)                           # a fresh odometer on the SAME camera: all ten pairs, exact
+    got4b = [(ok, odo4b.c_T_w.copy()) for ok in odo4b.run(iter(frames))]
+    assert len(got4b) == len(want) and not any(o is _RESERVED for o in cam4._slot_owner)
+    for (a, Ta), (b, Tb) in zip(got4b, want):
+        assert a == b and np.array_equal(Ta, Tb)
+    os.environ["VO_FAULT_SWEEP"] = "4"
+    c5, cam5 = _rig("C1", max_keypoints=500)
+    del os.environ["VO_FAULT_SWEEP"]
+    odo5 = StereoOdometer(cam5, **kw)
+    got5 = list(odo5.run(iter(frames), on_sweep_timeout="skip"))
+    assert got5.count(None) == 1 and got5[3] is None and len(got5) == len(frames)
+    assert not any(o is _RESERVED for o in cam5._slot_owner)
+    # a generator closed early gives its slots back too
+    g = odo5.run(iter(frames))
+    next(g)
+    g.close()
+    assert not any(o is _RESERVED for o in cam5._slot_owner) and cam5._ctx.lookahead_depth() == 0
     print("sweep-timeout body ok")
 
 
@@ -650,6 +685,24 @@ def test_engine_count_as_a_constructor_argument_bounds_the_footprint_and_changes
         chain(engines=0)
     cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), engines=1000, lookahead=99)
     assert 2 <= cam._ctx.set_engines(0) <= 24 and cam.lookahead == _native.VO_NUM_SLOTS - 3
+    cam._ctx.close()
+
+
+def test_staged_gray_pairs_narrower_than_the_disparity_range_keep_their_own_images():
+    """Width <= numDisparities: every pixel is INVALID and no cost kernel runs -- but on the in-place ingest path of staged
+    rectified gray pairs it is the first SGBM kernel that leaves the slot's copy of the pair behind, so the early return must
+    copy the images itself (it used to leave the PREVIOUS pair's images in the slot: ADVICE round 4)."""
+    c = Corridor("T0")
+    p = dict(c.sgbm_params(), numDisparities=128)
+    w = 96
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), p, (w, c.h), max_keypoints=300)
+    frames = [(np.ascontiguousarray(L[:, :w]), np.ascontiguousarray(R[:, :w])) for L, R in c.pairs(0, 5)]
+    staged = cam.stage_pairs(frames)
+    vr = cam.valid_region_left
+    for k in (0, 1, 2, 3, 4, 1):
+        xyz, disp, left = cam.compute_3d(staged[k], None, preprocessed=True)
+        assert np.array_equal(np.asarray(left), frames[k][0][vr[1]:vr[3], vr[0]:vr[2]]), k
+        assert (np.asarray(disp) == -1.0).all()                      # (minDisparity - 1) everywhere
     cam._ctx.close()
 
 

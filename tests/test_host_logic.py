@@ -183,3 +183,36 @@ def test_mono_odometer_speculation_bookkeeping(monkeypatch):
     assert out[0][1] == {"begun": 0, "used": 0, "void": 0}
     s = out[3][1]
     assert s["used"] >= 5 and s["void"] >= 2 and len(out[3][2]) > len(out[0][2])
+
+
+def test_shared_gpu_queue_budget_never_exceeds_the_hardware_queues():
+    """VO_SHARE_GPU=N: N processes' shares of the ~24 hardware queues must sum to <= 24 for every N up to 8 (they used to ask
+    for 6 each from N = 5 on: 8 ranks rehearsed on one GPU requested 48), and each share still holds a main stream, a pose
+    stream and an engine; N > 8 warns.  Runs `import openvo_amd` in a child process per N (the budget is read at import)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, json, warnings\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always')\n"
+            "    import openvo_amd\n"
+            "print(json.dumps(dict(q=os.environ.get('GPU_MAX_HW_QUEUES'), e=os.environ.get('VO_ENGINES'), p=os.environ.get('VO_POSE_STREAMS'),"
+            " la=os.environ.get('VO_LOOKAHEAD'), warned=len(w))))")
+    for n in (0, 2, 3, 4, 5, 6, 8, 12):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "VO_ENGINES", "VO_POSE_STREAMS", "VO_LOOKAHEAD")}
+        env["VO_SHARE_GPU"] = str(n)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        q = int(d["q"])
+        if n < 2:
+            assert q == 24 and d["e"] is None
+            continue
+        e, p = int(d["e"]), int(d["p"])
+        assert e >= 1 and p >= 1 and 1 + p + e <= q, d
+        if n <= 8:
+            assert n * q <= 24 and d["warned"] == 0, (n, d)
+        else:
+            assert d["warned"] == 1, (n, d)
