@@ -1505,16 +1505,6 @@ static int launch_diag(vo_ctx* ctx, const SgbmGeom& g, const int16_t* in1, int16
             return pad ? launch_diag_k<NP, true, 15, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 15, REV, WTA>(ctx, g, in1, sout, ctl);
         if (nwc == 11)
             return pad ? launch_diag_k<NP, true, 11, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 11, REV, WTA>(ctx, g, in1, sout, ctl);
-#ifdef VO_DIAG_EXTRA_WIDTHS
-        if (nwc == 9)
-            return pad ? launch_diag_k<NP, true, 9, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 9, REV, WTA>(ctx, g, in1, sout, ctl);
-        if (nwc == 10)
-            return pad ? launch_diag_k<NP, true, 10, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 10, REV, WTA>(ctx, g, in1, sout, ctl);
-        if (nwc == 12)
-            return pad ? launch_diag_k<NP, true, 12, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 12, REV, WTA>(ctx, g, in1, sout, ctl);
-        if (nwc == 13)
-            return pad ? launch_diag_k<NP, true, 13, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 13, REV, WTA>(ctx, g, in1, sout, ctl);
-#endif
     }
 
     return pad ? launch_diag_k<NP, true, 7, REV, WTA>(ctx, g, in1, sout, ctl) : launch_diag_k<NP, false, 7, REV, WTA>(ctx, g, in1, sout, ctl);

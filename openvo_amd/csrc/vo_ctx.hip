@@ -212,11 +212,13 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
         if (ctx->n_engines > ctx->engines_fit) ctx->n_engines = ctx->engines_fit;
     }
     if (const char* e9 = getenv("VO_POSE_STREAMS")) { int v = atoi(e9); if (v >= 1 && v <= vo_ctx::N_POSE_STREAMS) ctx->n_pose_streams = v; }
+    if (const char* e27 = getenv("VO_STAGGER")) ctx->tune_stagger = atoi(e27);
+    if (const char* e25 = getenv("VO_DIAG_WAVES")) { const int v = atoi(e25); ctx->tune_diag_nwc = (v == 7 || v == 11 || v == 15) ? v : 0; }   // the three strip widths that are built
+#ifdef VO_TEST_HOOKS
+    // development switches live in the test-only build alone (libvo355_hooks.so; tools/stage_ablation.py loads it): some of them
+    // switch stages or the strip hand-off OFF, and nothing in a user's environment may make the product compute garbage
     if (const char* e27 = getenv("VO_DIAG_WGS")) ctx->tune_diag_wgs = atoi(e27);
     if (const char* e26 = getenv("VO_DIAG_DEBUG")) ctx->tune_diag_dbg = atoi(e26);
-    if (const char* e27 = getenv("VO_STAGGER")) ctx->tune_stagger = atoi(e27);
-    if (const char* e25 = getenv("VO_DIAG_WAVES")) ctx->tune_diag_nwc = (atoi(e25) >= 7 && atoi(e25) <= 15) ? atoi(e25) : 0;   // (7, 11, 15 are built; others fall back to 7 unless VO_DIAG_EXTRA_WIDTHS)
-#ifdef VO_TEST_HOOKS
     if (const char* e10 = getenv("VO_FAULT_PREFETCH")) ctx->fault_prefetch = atoi(e10);   // test-only build (libvo355_hooks.so)
     if (const char* e11 = getenv("VO_FAULT_SWEEP")) ctx->fault_sweep = atoi(e11);
 #endif

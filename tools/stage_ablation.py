@@ -31,5 +31,7 @@ VARIANTS = (("complete", 0), ("no cost", 4), ("no W+E", 8), ("no diagonal", 16),
 engines = sys.argv[1].split(",") if len(sys.argv) > 1 else ["12"]
 for tag, dbg in VARIANTS:
     for n in engines:
-        e = dict(os.environ, TAG="%s, %s engines" % (tag, n), VO_DIAG_DEBUG=str(dbg), VO_ENGINES=n)
+        # the stage switches exist in the test-only build alone (libvo355_hooks.so)
+        hooks = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "openvo_amd", "libvo355_hooks.so")
+        e = dict(os.environ, TAG="%s, %s engines" % (tag, n), VO_DIAG_DEBUG=str(dbg), VO_ENGINES=n, VO355_LIB=os.path.abspath(hooks))
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=e, timeout=300)
