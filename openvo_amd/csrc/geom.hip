@@ -252,37 +252,61 @@ extern "C" int vo_ratio_filter(const int32_t* idx, const int32_t* dist, int nq, 
     return VO_OK;
 }
 
-// ratio test + ordered compaction on the device: one block (any multiple of 64 threads up to 1024), ballot prefix per
-// wave, wave counts carried through LDS
+// ratio test + ordered compaction on the device: one block (any multiple of 64 threads up to 1024).  Batches of up to eight
+// elements per thread (element i0 + k * blockDim + thread): all their loads are in flight together, the keep flags become
+// ballots, the per-(batch row, wave) counts go through LDS where the first wave turns them into exclusive offsets (one
+// wave-wide prefix over 128 counts), and the survivors' coordinates are gathered and stored.  Three global round trips per
+// 8192 queries (the one-element-per-thread loop this replaces paid three per 1024: 22 us at 8000 queries, now 6).
 __global__ void __launch_bounds__(1024) k_ratio_compact(const int32_t* __restrict__ idx, const int32_t* __restrict__ dist, int nq, double ratio,
                                                         const float* __restrict__ xy_q, const float* __restrict__ xy_t, int32_t* __restrict__ q_out,
                                                         int32_t* __restrict__ t_out, float* __restrict__ xyq_out, float* __restrict__ xyt_out,
                                                         int32_t* __restrict__ m_out)
 {
-    __shared__ int s_cnt[16];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    constexpr int K = 8;
+    __shared__ int s_cnt[K * 16 + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
     int base = 0;
-    for (int i0 = 0; i0 < nq; i0 += blockDim.x) {
-        const int i = i0 + threadIdx.x;
-        bool keep = false;
-        int t = -1;
-        if (i < nq) {
-            t = idx[2 * i];
-            double a = (double)(float)dist[2 * i], b = (double)(float)dist[2 * i + 1];
-            keep = idx[2 * i + 1] >= 0 && a < ratio * b;
+    for (int i0 = 0; i0 < nq; i0 += K * nt) {
+        int2 id[K], ds[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int i = i0 + k * nt + threadIdx.x;
+            id[k] = make_int2(-1, -1); ds[k] = make_int2(0, 0);
+            if (i < nq) { id[k] = ((const int2*)idx)[i]; ds[k] = ((const int2*)dist)[i]; }
         }
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) s_cnt[wv] = __popcll(bal);
+        unsigned long long bal[K];
+        float2 pq[K], pt[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int i = i0 + k * nt + threadIdx.x;
+            const double a = (double)(float)ds[k].x, b = (double)(float)ds[k].y;
+            const bool keep = i < nq && id[k].y >= 0 && a < ratio * b;
+            bal[k] = __ballot(keep);
+            if (lane == 0) s_cnt[k * nw + wv] = __popcll(bal[k]);
+            pq[k] = make_float2(0.f, 0.f); pt[k] = pq[k];
+            if (keep) { pq[k] = ((const float2*)xy_q)[i]; pt[k] = ((const float2*)xy_t)[id[k].x]; }    // (in flight across the barriers)
+        }
         __syncthreads();
-        int before = 0, total = 0;
-        for (int k = 0; k < nw; k++) { const int c = s_cnt[k]; before += k < wv ? c : 0; total += c; }
-        if (keep) {
-            const int pos = base + before + __popcll(bal & ((1ull << lane) - 1ull));
-            q_out[pos] = i; t_out[pos] = t;
-            xyq_out[2 * pos] = xy_q[2 * i]; xyq_out[2 * pos + 1] = xy_q[2 * i + 1];
-            xyt_out[2 * pos] = xy_t[2 * t]; xyt_out[2 * pos + 1] = xy_t[2 * t + 1];
+        if (wv == 0) {                                   // exclusive prefix over the K * nw <= 128 counts, in (batch row, wave) order
+            const int n = K * nw;
+            const int c0 = 2 * lane < n ? s_cnt[2 * lane] : 0, c1 = 2 * lane + 1 < n ? s_cnt[2 * lane + 1] : 0;
+            int inc = c0 + c1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+            const int ex = inc - (c0 + c1);
+            if (2 * lane < n) s_cnt[2 * lane] = ex;
+            if (2 * lane + 1 < n) s_cnt[2 * lane + 1] = ex + c0;
+            if (lane == 63) s_cnt[K * 16] = inc;
         }
-        base += total;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            if ((bal[k] >> lane) & 1ull) {
+                const int pos = base + s_cnt[k * nw + wv] + __popcll(bal[k] & ((1ull << lane) - 1ull));
+                q_out[pos] = i0 + k * nt + threadIdx.x; t_out[pos] = id[k].x;
+                ((float2*)xyq_out)[pos] = pq[k]; ((float2*)xyt_out)[pos] = pt[k];
+            }
+        base += s_cnt[K * 16];
         __syncthreads();
     }
     if (threadIdx.x == 0) *m_out = base;
@@ -1376,7 +1400,8 @@ static int pose_alt_prepare(vo_ctx* ctx, int k)
     p.stream = shared;                            // (not owned by the alternate)
     VO_HIP(ctx, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     VO_HIP(ctx, hipHostMalloc(&p.result, 1024, hipHostMallocDefault));
-    VO_HIP(ctx, hipMalloc((void**)&p.mw.m_idx, cap * 8 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.mw.m_dist, cap * 8 + 256));
+    VO_HIP(ctx, hipMalloc((void**)&p.mw.m_idx, cap * 8 + 256));
+    if (match_dist_alloc(ctx, &p.mw.m_dist)) return vo_fail(ctx, VO_E_HIP, "asynchronous pose step: allocation failed");
     VO_HIP(ctx, hipMalloc((void**)&p.mw.m_count, 256));
     VO_HIP(ctx, hipMalloc((void**)&p.mw.mq_idx, cap * 4 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.mw.mt_idx, cap * 4 + 256));
     VO_HIP(ctx, hipMalloc((void**)&p.mw.pts_a, cap * 12 + 256)); VO_HIP(ctx, hipMalloc((void**)&p.mw.pts_b, cap * 12 + 256));

@@ -463,9 +463,10 @@ static int mono_alt_prepare(vo_ctx* ctx, int k)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p.done, hipEventDisableTiming);
     p.result_bytes = MONO_HDR + cap * (1 + 4 + 4 + 8) + 64;
     if (e == hipSuccess) e = hipHostMalloc((void**)&p.result, p.result_bytes, hipHostMallocDefault);
-    void** ps[] = { (void**)&p.mw.m_idx, (void**)&p.mw.m_dist, (void**)&p.mw.m_count, (void**)&p.mw.mq_idx, (void**)&p.mw.mt_idx, (void**)&p.mw.xy_a, (void**)&p.mw.xy_b };
-    const size_t sz[] = { cap * 8, cap * 8, 256, cap * 4, cap * 4, cap * 8, cap * 8 };
+    void** ps[] = { (void**)&p.mw.m_idx, (void**)&p.mw.m_count, (void**)&p.mw.mq_idx, (void**)&p.mw.mt_idx, (void**)&p.mw.xy_a, (void**)&p.mw.xy_b };
+    const size_t sz[] = { cap * 8, 256, cap * 4, cap * 4, cap * 8, cap * 8 };
     for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]) && e == hipSuccess; i++) e = hipMalloc(ps[i], sz[i] + 256);
+    if (e == hipSuccess && match_dist_alloc(ctx, &p.mw.m_dist)) e = hipErrorOutOfMemory;
     if (e != hipSuccess) {
         mono_alt_release(p);                      // a partly built alternate is given back whole
         return vo_fail(ctx, VO_E_HIP, "asynchronous monocular step: allocation failed: %s", hipGetErrorString(e));

@@ -181,7 +181,8 @@ extern "C" int vo_create(int device_id, int max_w, int max_h, int max_disp, int 
     DALLOC(ctx->mw->m_count, 64);
     DALLOC(ctx->host_mask_dev, npx);
     DALLOC(ctx->mq, (size_t)ctx->kp_cap * 32); DALLOC(ctx->mt, (size_t)ctx->kp_cap * 32);
-    DALLOC(ctx->mw->m_idx, (size_t)ctx->kp_cap * 2); DALLOC(ctx->mw->m_dist, (size_t)ctx->kp_cap * 2);
+    DALLOC(ctx->mw->m_idx, (size_t)ctx->kp_cap * 2);
+    if (match_dist_alloc(ctx, &ctx->mw->m_dist)) { g_create_err = "hipMalloc failed (match scratch)"; vo_destroy(ctx); return VO_E_HIP; }
     DALLOC(ctx->mw->pts_a, (size_t)ctx->kp_cap * 3); DALLOC(ctx->mw->pts_b, (size_t)ctx->kp_cap * 3);
     DALLOC(ctx->mw->st_a, ctx->kp_cap); DALLOC(ctx->mw->st_b, ctx->kp_cap);
     DALLOC(ctx->mw->xy_a, (size_t)ctx->kp_cap * 2); DALLOC(ctx->mw->xy_b, (size_t)ctx->kp_cap * 2);

@@ -327,6 +327,15 @@ int orb_prepare_tables(vo_ctx* ctx, int w, int h);
 int orb_run(vo_ctx* ctx, FrameSlot* fs, const uint8_t* d_img, int img_stride, int w, int h,
             int nfeatures, int mask_mode, const int16_t* d_disp16, int disp_stride, int min_d16,
             int max_d16, const uint8_t* d_mask, int mask_stride);
+// the kNN kernel's scratch lives behind the distances in ONE allocation (MatchWs::m_dist): 2 distances per query, then up to
+// VO_KNN_SPLITS partial (best, second) pairs per query, then one ticket word per 64 queries (zero between launches)
+#define VO_KNN_SPLITS 16
+static inline size_t match_dist_bytes(int kp_cap)
+{
+    const size_t capq = ((size_t)kp_cap + 63) & ~(size_t)63;
+    return capq * 8 + (size_t)VO_KNN_SPLITS * capq * 8 + (capq / 64 + 1) * 4 + 256;
+}
+int match_dist_alloc(vo_ctx* ctx, int32_t** p);      // hipMalloc + the tickets cleared
 int match_knn2(vo_ctx* ctx, const uint8_t* dq, int nq, const uint8_t* dt, int nt, int32_t* d_idx,
                int32_t* d_dist);
 int points3d_launch(vo_ctx* ctx, const int16_t* d_disp16, int w, int h, const float* d_xy, int n,
