@@ -268,7 +268,7 @@ int vo_ransac_pnp(vo_ctx* ctx, const float* pts3d, const float* pts2d, int n, co
 /* hipEvent timing of the kernels launched on the context stream (events are recorded without
  * blocking and resolved by vo_get_timings).  Stage ids: */
 enum { VO_T_UPLOAD = 0, VO_T_SGBM_COST, VO_T_SGBM_AGG, VO_T_SGBM_WTA, VO_T_SGBM_POST, VO_T_ORB,
-       VO_T_MATCH, VO_T_POSE, VO_T_NSTAGES };
+       VO_T_MATCH, VO_T_POSE, VO_T_KNN /* the Hamming kNN kernel alone (inside VO_T_MATCH or VO_T_POSE) */, VO_T_NSTAGES };
 /* on = 0 off, 1 every stage, otherwise (stage bit mask << 1), e.g. (1 << VO_T_SGBM_AGG) << 1 */
 int vo_enable_timing(vo_ctx* ctx, int on);
 /* accumulated milliseconds and launch counts per stage since the last reset */

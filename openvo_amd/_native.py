@@ -18,7 +18,7 @@ VO_NUM_HOST_STAGE = 20
 VO_NUM_MONO_ASYNC = 5
 VO_NUM_POSE_ASYNC = 8
 SCHED_DIAG, SCHED_DIAG_RAGGED, SCHED_UNFUSED = 1, 2, 3
-T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose")
+T_STAGES = ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose", "knn")
 
 # every symbol include/vo355.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

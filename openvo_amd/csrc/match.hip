@@ -231,6 +231,7 @@ int match_knn2(vo_ctx* ctx, const uint8_t* dq, int nq, const uint8_t* dt, int nt
             attr_set |= 1ull << (ctx->device & 63);
         }
     }
+    StageTimer tk(ctx, VO_T_KNN);
     hipLaunchKernelGGL(k_bf_knn2, dim3(gblocks * splits), dim3(KNN_WAVES * 64), lds, ctx->stream, dq, nq, dt, nt, splits, per, groups, part,
                        tickets, d_idx, d_dist);
     VO_CHECK_LAUNCH(ctx);
