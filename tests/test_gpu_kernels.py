@@ -97,6 +97,36 @@ def test_sgbm_random_noise_images(oracle, ctx_small):
     assert np.array_equal(ctx_small.sgbm_compute_host(Z, Z), oracle.sgbm_compute(Z, Z, p, 0))
 
 
+def test_bf_knn2_tile_and_slice_edges_and_adversarial_bit_patterns(oracle):
+    """The matcher computes popcount(q ^ t) as |q| + |t| - 2 q.t on the matrix cores (int8 contraction of the bits), walks the
+    train set in tiles of 16 descriptors, cuts it into up to 16 slices merged through a ticket, and serves 8 groups of 64
+    queries per workgroup: sizes around every one of those boundaries (incl. a train set larger than one LDS chunk of 512 x 16
+    slices), all-zero / all-one / single-bit descriptors (norms 0 and 256, dot products 0 and 256), duplicated train
+    descriptors (ties -> lower index) and identical query / train sets -- every index and distance equal to the oracle's."""
+    from openvo_amd import _native
+    ctx = _native.Context(0, 640, 480, 64, 9000)
+    rng = np.random.default_rng(77)
+    sizes = [(64, 16), (65, 17), (63, 15), (512, 512), (513, 511), (130, 33), (3, 1), (5, 2), (700, 17), (1, 4097), (2, 8200),
+             (1100, 2050), (8012, 8030), (576, 9000)]
+    for nq, nt in sizes:
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        q[0] = 0; t[0] = 255                                  # |q| = 0 against |t| = 256: distance 256, the largest
+        if nq > 2:
+            q[1] = 255; q[2] = 0; q[2, 17] = 0x10             # all ones; a single bit
+        if nt > 9:
+            t[7] = t[2]; t[9] = 0                             # a duplicate (tie -> index 2 first); all zeros
+            t[nt - 1] = t[nt - 2]                             # a tie across the last tile's end
+        gi, gd = ctx.bf_knn2(q, t)
+        ri, rd = oracle.bf_knn2_hamming(q, t)
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd), (nq, nt)
+    d = rng.integers(0, 256, (700, 32), dtype=np.uint8)      # a set against itself: best = itself at distance 0
+    gi, gd = ctx.bf_knn2(d, d)
+    ri, rd = oracle.bf_knn2_hamming(d, d)
+    assert np.array_equal(gi, ri) and np.array_equal(gd, rd) and (gd[:, 0] == 0).all()
+    ctx.close()
+
+
 @pytest.mark.parametrize("nq,nt", [(500, 500), (1, 2), (7, 1), (3, 0), (1000, 777)])
 def test_bf_knn2_bit_exact(oracle, ctx_small, nq, nt):
     rng = np.random.default_rng(nq * 1000 + nt)
