@@ -143,7 +143,7 @@ def bench_stereo(args, group, device, workload, K, W, light):
     # kernel only: event packets around every small stage would perturb the throughput measured
     ctx.enable_timing(not args.no_events, stages=["sgbm_wta"])
     ctx.timings(reset=True)
-    rel, acc, dts = [], [], []
+    rel, acc, dts, clocks = [], [], [], []
 
     def window(od, lo, n, record):
         """n update() steps on staged[lo : lo + n] from a cold start: every stream drained and every look-ahead result
@@ -167,6 +167,8 @@ def bench_stereo(args, group, device, workload, K, W, light):
                     rel.append(sharding.relative_from_chain(before, od.c_T_w) if ok else np.eye(4))
         ctx.synchronize()                         # every stream of this rank's context has drained: this rank's n steps are done
         dt = time.perf_counter() - t0             # (the MAX over ranks is taken below; the closing barrier is not part of any rank's work)
+        if record:
+            clocks.append(round(ctx.shader_clock(200), 0))   # after the clock has stopped: the shader clock this window ended at
         group.barrier()
         cam.lookahead_stop = None
         return dt
@@ -297,7 +299,7 @@ def bench_stereo(args, group, device, workload, K, W, light):
         P = 8 if workload == "C4" else 5
         alg_bytes = 2.0 * cells * npaths          # the int16 cost volume read once per direction the kernel covers (3)
         survey_bytes = 2.0 * cells * (1 + P)      # A_sgbm = 2 B * V * (1 + P) for the whole pair
-        traffic, per_pair, traffic_rev, valu_pp = None, None, "unknown", None
+        traffic, per_pair, traffic_rev, valu_pp, traffic_stale = None, None, "unknown", None, None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
         if os.path.exists(tf):
             try:
@@ -305,6 +307,8 @@ def bench_stereo(args, group, device, workload, K, W, light):
                 traffic, per_pair = tj.get("dominant_kernel_bytes_per_launch"), tj.get("sgbm_bytes_per_pair")
                 valu_pp = tj.get("valu_wave_instructions_per_pair")
                 traffic_rev = tj.get("source", "unknown")
+                from openvo_amd._native import csrc_digest
+                traffic_stale = tj.get("csrc_digest") != csrc_digest()     # the counters were taken from other kernel sources (or carry no stamp)
                 if not isinstance(per_pair, (int, float)):        # (a profile file of an older layout)
                     per_pair = None
             except Exception:
@@ -315,6 +319,7 @@ def bench_stereo(args, group, device, workload, K, W, light):
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "bytes_per_launch": alg_bytes,
                 "traffic_source": ("committed file profiles/traffic_%s.json, NOT measured in this run (PMC counters need rocprofv3 "
                                    "around the process): %s" % (workload, traffic_rev)) if traffic is not None else None,
+                "traffic_stale": traffic_stale,      # True: profiles/traffic_<workload>.json was taken from other kernel sources than these
                 "schedule_counts": {schedule: R * K}}
         if tb is not None:
             def alone(t):
@@ -383,6 +388,9 @@ def bench_stereo(args, group, device, workload, K, W, light):
             # stream drained and all look-ahead work dropped before each clock starts); the samples, in order:
             "window_values": [round(K * world / d, 2) for d in dt_windows],
             "window_ms": [round(1e3 * d, 3) for d in dt_windows],
+            # the shader clock (MHz) rank 0 read right after each window's clock had stopped (vo_shader_clock: one wave, 200 us):
+            # a GPU that was idle before the run ramps its clock over the first windows
+            "window_clock_mhz": clocks[:len(dt_windows)],
             "cores_per_rank": cores_per_rank(world),
         }
         if dt_default:

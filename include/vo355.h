@@ -286,6 +286,10 @@ int vo_sgbm_last_schedule(vo_ctx* ctx, int* schedule_out);
  * whole one) between two of the context's volumes, timed with HIP events; *gb_per_s counts bytes read + bytes written.
  * Overwrites the cost volume: call it between, not inside, vo_sgbm_compute / vo_prefetch_pair sequences. */
 int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemporal, double* gb_per_s);
+/* the shader clock the GPU holds right now (MHz): one wave counts its cycles (s_memtime) against the 100 MHz wall counter
+ * (s_memrealtime) for `micros` microseconds on the context's main stream; synchronous.  Measurement aid (bench.py records it
+ * after every timed window: a GPU that has been idle ramps its clock up over the first tens of milliseconds of work). */
+int vo_shader_clock(vo_ctx* ctx, int micros, double* mhz);
 /* health of the diagonal aggregation sweeps (synchronises): *error_out = number of SGBM runs of this context in which a wait
  * between strips exceeded its poll limit (the affected pair's results are refused with VO_E_SWEEP where they are picked up:
  * vo_sgbm_compute with an output pointer, vo_download_disparity_f32 / _xyz, vo_orb_detect_and_compute with the fused mask,

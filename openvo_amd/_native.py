@@ -31,7 +31,7 @@ SYMBOLS = [
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints", "vo_download_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_essential5", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
-    "vo_sgbm_last_geometry", "vo_host_stage_pair", "vo_host_stage_fetch", "vo_prefetch_host_staged", "vo_lookahead_depth", "vo_lookahead_drop", "vo_sgbm_last_schedule", "vo_measure_copy", "vo_sgbm_sweep_status", "vo_sgbm_sweep_stats",
+    "vo_sgbm_last_geometry", "vo_host_stage_pair", "vo_host_stage_fetch", "vo_prefetch_host_staged", "vo_lookahead_depth", "vo_lookahead_drop", "vo_sgbm_last_schedule", "vo_measure_copy", "vo_shader_clock", "vo_sgbm_sweep_status", "vo_sgbm_sweep_stats",
     "vo_upload_mono", "vo_prefetch_staged_mono", "vo_mono_pair", "vo_mono_pair_begin", "vo_mono_pair_end", "vo_slot_ready", "vo_host_stage_begin", "vo_host_stage_wait",
     "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_info", "vo_mgpu_last_error",
     "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
@@ -78,6 +78,18 @@ def _image(img):
     if a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
         raise ValueError("an image must be HxW or HxWx3 (got shape %s)" % (a.shape,))
     return _c(a, np.uint8), (3 if a.ndim == 3 else 1)
+
+
+def csrc_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.inc, *.h + the public header), in name order: stamps a profile with the code it
+    was taken from (tools/profile_round.sh) and lets bench.py say when the committed counters describe other kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(_CSRC) if f.endswith((".hip", ".inc", ".h")))
+    for path in [os.path.join(_CSRC, f) for f in names] + [os.path.join(_HERE, "..", "include", "vo355.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build_native(force=False):
@@ -162,6 +174,7 @@ def lib():
         L.vo_sgbm_last_schedule.argtypes = [vp, vp]
         L.vo_sgbm_sweep_stats.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
         L.vo_measure_copy.argtypes = [vp, ctypes.c_int64, ci, ci, vp]
+        L.vo_shader_clock.argtypes = [vp, ci, vp]
         L.vo_upload_mono.argtypes = [vp, ci, vp, ci, ci, ci]
         L.vo_prefetch_staged_mono.argtypes = [vp, ci, ci, ci]
         L.vo_mono_pair.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, ci, vp, vp, vp, vp, vp, ci]
@@ -676,6 +689,12 @@ class Context:
         """GB/s (read + written) of a streaming device copy between two of the context's volumes."""
         g = ctypes.c_double(0.0)
         self._ck(self._lib.vo_measure_copy(self._h, int(nbytes), int(reps), 1 if nontemporal else 0, ctypes.byref(g)))
+        return g.value
+
+    def shader_clock(self, micros=200):
+        """MHz the shader clock holds right now (one wave counting cycles against the 100 MHz wall counter for `micros` us)."""
+        g = ctypes.c_double(0.0)
+        self._ck(self._lib.vo_shader_clock(self._h, int(micros), ctypes.byref(g)))
         return g.value
 
     def sgbm_last_geometry(self):

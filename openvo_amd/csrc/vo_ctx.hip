@@ -1200,6 +1200,34 @@ extern "C" int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemp
     return VO_OK;
 }
 
+__global__ void k_clock_probe(unsigned long long* out, unsigned long long ticks)
+{
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long w = w0;
+    unsigned v = threadIdx.x;
+    while (w - w0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 64; i++) asm volatile("v_pk_add_i16 %0, %0, %0" : "+v"(v));
+        w = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w - w0; out[2] = v; }
+}
+
+extern "C" int vo_shader_clock(vo_ctx* ctx, int micros, double* mhz)
+{
+    if (!ctx || !mhz || micros <= 0 || micros > 1000000) return vo_fail(ctx, VO_E_ARG, "vo_shader_clock: bad argument");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long* d = (unsigned long long*)ctx->red;              // (reduction scratch: nothing of the pipeline keeps state in it)
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, ctx->stream, d, (unsigned long long)micros * 100ull);
+    VO_CHECK_LAUNCH(ctx);
+    unsigned long long h[2] = { 0, 0 };
+    VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VO_HIP(ctx, hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+    *mhz = h[1] ? (double)h[0] / ((double)h[1] / 100.0) : 0.0;           // cycles per microsecond
+    return VO_OK;
+}
+
 // timeline of the latest diagonal sweep in the main workspace (development aid): words [8 + 8 s ..] of control block `block`
 // = {start, end, failed polls, ticks waiting, misses} of strip s in 100 MHz ticks
 extern "C" int vo_sgbm_sweep_stats(vo_ctx* ctx, int block, int32_t* out, int n_words)

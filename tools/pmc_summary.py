@@ -16,8 +16,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_%s" % tag)
 dst = os.path.join(root, "profiles")
 low = wl.lower()
+digest = None
+if os.path.exists(os.path.join(src, "csrc_digest.txt")):
+    digest = open(os.path.join(src, "csrc_digest.txt")).read().strip() or None
 for pat, name in (("stats/**/*kernel_stats.csv", "%s_kernel_stats_%s.csv" % (tag, low)),
-                  ("alone/**/*kernel_stats.csv", "%s_kernel_stats_alone_%s.csv" % (tag, low))):
+                  ("alone/**/*kernel_stats.csv", "%s_kernel_stats_alone_%s.csv" % (tag, low)),
+                  ("alone_engine/**/*kernel_stats.csv", "%s_kernel_stats_alone_engine_%s.csv" % (tag, low))):
     f = glob.glob(os.path.join(src, pat), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, name))
@@ -64,7 +68,7 @@ if o:
     # vector instructions of ALL kernels of a pair (SQ_INSTS_VALU counts wave-instructions), from the occupancy pass
     n_occ = max(len(v) for (c, k), v in o.items() if c == "SQ_INSTS_VALU" and k.startswith(("k_sgbm_planes", "k_orb_pyramid")))
     valu_per_pair = int(sum(sum(v) for (c, k), v in o.items() if c == "SQ_INSTS_VALU" and k.startswith("k_")) / n_occ)
-json.dump({"workload": wl,
+json.dump({"workload": wl, "csrc_digest": digest, "tag": tag,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 6 --warmup 2 --cpu-pairs 0 --no-post` "
                      "(tools/profile_round.sh %s), MI355X, default schedule (W + E volume, diagonal sweep)" % tag,
            "correction": "gfx950: FETCH_SIZE counts wide coalesced (16 B/lane) reads at half -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
