@@ -333,24 +333,37 @@ def device_count():
 
 
 def init_from_env(want_rccl=True):
-    """Group of the ranks a launcher started on this node (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR,
-    MASTER_PORT); returns (group, device index for this rank).  With fewer GPUs than ranks (rehearsal on a
-    one-GPU box) ranks share devices and everything stays on the socket transport."""
+    """Group of the ranks a launcher started on this node (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR,
+    MASTER_PORT); returns (group, device index for this rank).
+
+    The device index is an index into the devices THIS process sees, which a launcher may have masked
+    (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES):
+      * at least as many visible devices as ranks on the node: rank r takes visible device LOCAL_RANK -- whatever physical GPUs
+        the mask names (`HIP_VISIBLE_DEVICES=4,5,6,7` with four ranks: LOCAL_RANK 0..3 -> physical 4..7);
+      * a mask that leaves each rank fewer devices than there are ranks (typically ONE device per rank, a different one for
+        each): LOCAL_RANK modulo the visible count, i.e. device 0 of a one-device mask -- LOCAL_RANK is then NOT a device index;
+      * fewer devices than ranks and no mask: refused, unless the ranks say they mean to share (VO_SHARE_GPU, a rehearsal).
+    RCCL is attached when every rank can have a GPU of its own (enough visible devices, or a per-rank mask and no VO_SHARE_GPU);
+    two ranks that do land on one GPU make the communicator's creation fail, and the creation vote then leaves ALL ranks on the
+    socket transport together (Group.attach_rccl)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)) or world)
     g = Group(rank, world)
     ndev = device_count()
     masked = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
-    if world > 1 and 0 < ndev < world and not masked and os.environ.get("VO_SHARE_GPU", "0") in ("", "0"):
+    sharing = os.environ.get("VO_SHARE_GPU", "0") not in ("", "0")
+    if world > 1 and 0 < ndev < local_world and not masked and not sharing:
         # several ranks on one GPU oversubscribe its hardware queues (12 engines each: measured 96 pairs/s instead of 1400);
         # a launcher that gives every rank a device of its own masks them per rank.  Rehearsals opt in with
         # VO_SHARE_GPU=<ranks per GPU>, set BEFORE openvo_amd is imported: every rank then takes its share of the queues.
         g.close()
         raise RuntimeError("%d ranks but only %d visible GPU(s) and no per-rank device mask: refusing to share a GPU "
-                           "(set VO_SHARE_GPU=<ranks per GPU> in the ranks' environment for a rehearsal)" % (world, ndev))
-    device = local if ndev >= world else local % max(ndev, 1)
-    if want_rccl and world > 1 and ndev >= world and os.environ.get("VO_NO_RCCL", "0") != "1":
+                           "(set VO_SHARE_GPU=<ranks per GPU> in the ranks' environment for a rehearsal)" % (local_world, ndev))
+    device = local if ndev >= local_world else local % max(ndev, 1)
+    own_gpu = ndev >= local_world or (masked and not sharing and ndev > 0)
+    if want_rccl and world > 1 and own_gpu and os.environ.get("VO_NO_RCCL", "0") != "1":
         g.attach_rccl(device)
     return g, device
 

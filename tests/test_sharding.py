@@ -337,6 +337,57 @@ def test_more_ranks_than_gpus_is_refused_without_a_mask(monkeypatch):
     assert dev == 0 and g.world == 2
 
 
+def test_rank_to_device_binding_under_device_masks(monkeypatch):
+    """LOCAL_RANK is an index into the devices a rank SEES, not a physical GPU number, and under a one-device-per-rank mask it is
+    no device index at all.  Every combination a launcher can produce on one node, with stand-ins for the device count, the
+    group and the RCCL attach (which records the device it was asked for)."""
+    attached = []
+
+    class FakeGroup:
+        def __init__(self, rank, world):
+            self.rank, self.world = rank, world
+        def close(self):
+            pass
+        def attach_rccl(self, device):
+            attached.append(device)
+    monkeypatch.setattr(sharding, "Group", FakeGroup)
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "VO_SHARE_GPU", "VO_NO_RCCL", "LOCAL_WORLD_SIZE"):
+        monkeypatch.delenv(v, raising=False)
+
+    def bind(world, local, ndev, mask=None, share=None, rank=None, local_world=None):
+        monkeypatch.setenv("WORLD_SIZE", str(world))
+        monkeypatch.setenv("RANK", str(local if rank is None else rank))
+        monkeypatch.setenv("LOCAL_RANK", str(local))
+        for name, val in (("HIP_VISIBLE_DEVICES", mask), ("VO_SHARE_GPU", share), ("LOCAL_WORLD_SIZE", local_world)):
+            if val is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, str(val))
+        monkeypatch.setattr(sharding, "device_count", lambda: ndev)
+        del attached[:]
+        g, dev = sharding.init_from_env()
+        return dev, list(attached)
+
+    # the driver's launch: 8 ranks, 8 visible GPUs, no mask: device = LOCAL_RANK, RCCL on that device
+    assert [bind(8, r, 8) for r in range(8)] == [(r, [r]) for r in range(8)]
+    # a node-wide mask naming OTHER physical GPUs (4,5,6,7 for four ranks): still visible device LOCAL_RANK (0..3)
+    assert [bind(4, r, 4, mask="4,5,6,7") for r in range(4)] == [(r, [r]) for r in range(4)]
+    # more visible devices than ranks: LOCAL_RANK
+    assert bind(2, 1, 8) == (1, [1])
+    # a per-rank mask of ONE device (rank r sees only physical GPU r): LOCAL_RANK 5 is NOT a device index -- device 0, RCCL attached
+    assert [bind(8, r, 1, mask=str(r)) for r in (0, 5, 7)] == [(0, [0])] * 3
+    # a per-rank mask of two devices for eight ranks (two ranks per pair of GPUs would be LOCAL_RANK % 2)
+    assert bind(8, 5, 2, mask="2,3") == (1, [1])
+    # RANK != LOCAL_RANK (second node of a two-node job would say RANK 11, LOCAL_RANK 3, LOCAL_WORLD_SIZE 8): the device follows LOCAL_RANK
+    assert bind(16, 3, 8, rank=11, local_world=8) == (3, [3])
+    # a rehearsal on one GPU (VO_SHARE_GPU): everybody on device 0, no RCCL -- with or without a mask
+    assert bind(8, 5, 1, share=8) == (0, [])
+    assert bind(8, 5, 1, mask="0", share=8) == (0, [])
+    # no mask, fewer GPUs than ranks, nobody said "share": refused
+    with pytest.raises(RuntimeError, match="refusing to share a GPU"):
+        bind(8, 5, 4)
+
+
 def test_bench_orchestration_with_eight_socket_ranks(tmp_path):
     """bench.py --gpus 8 as the driver launches it (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), with the
     GPU work replaced by stand-ins (tests/bench_standin.py): eight ranks render their frames at the same time (the synthetic
