@@ -80,7 +80,7 @@ def main():
             # their own complete JSON objects (shorter windows), so that the driver's one command observes them too
             other = {}
             for name, fn in (("C4", lambda: bench_stereo(args, group, device, "C4", 12, 4, light=True)),
-                             ("C5", lambda: bench_c5(args, group, device, 100, 5))):
+                             ("C5", lambda: bench_c5(args, group, device, 200, 12))):
                 try:
                     other[name] = fn()
                 except Exception as e:                      # a failure here must not cost the headline line

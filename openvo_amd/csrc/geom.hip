@@ -1442,7 +1442,11 @@ extern "C" int vo_pose_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
         if (!ctx->pose_alt[(ctx->pose_next + i) % vo_ctx::N_POSE_ALT].busy) k = (ctx->pose_next + i) % vo_ctx::N_POSE_ALT;
     if (k < 0) return vo_fail(ctx, VO_E_STATE, "vo_pose_pair_begin: every asynchronous pose step is still open (end one first)");
     vo_ctx::PoseAlt& p = ctx->pose_alt[k];
-    if ((rc = pose_alt_prepare(ctx, k))) return rc;
+    // the first step begun builds EVERY alternate (a dozen allocations, a pinned record and an event each: ~1 ms apiece): built one
+    // by one as the round-robin first reaches them, the later ones fell into whatever the caller was timing by then (the first two
+    // of bench.py's five cold windows read 10 % low)
+    for (int i = 0; i < vo_ctx::N_POSE_ALT; i++)
+        if ((rc = pose_alt_prepare(ctx, (k + i) % vo_ctx::N_POSE_ALT))) return rc;
     FrameSlot& a = ctx->slots[slot_a];
     FrameSlot& b = ctx->slots[slot_b];
     PoseOut* rec = (PoseOut*)p.result;

@@ -204,7 +204,10 @@ int match_dist_alloc(vo_ctx* ctx, int32_t** p)
 {
     const size_t n = match_dist_bytes(ctx->kp_cap);
     if (hipMalloc((void**)p, n) != hipSuccess) { *p = nullptr; return VO_E_HIP; }
-    if (hipMemset(*p, 0, n) != hipSuccess) return VO_E_HIP;
+    // (the tickets must read zero before the first launch on WHATEVER stream uses this scratch: the alternates' streams do not
+    // synchronise with the null stream the memset runs on, and a memset landing in the middle of a launch clears tickets that
+    // have been drawn -- the group's result is then never written)
+    if (hipMemsetAsync(*p, 0, n, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return VO_E_HIP;
     return VO_OK;
 }
 

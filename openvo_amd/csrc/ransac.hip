@@ -492,7 +492,8 @@ extern "C" int vo_mono_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
         if (!ctx->mono_alt[(ctx->mono_next + i) % vo_ctx::N_MONO_ALT].busy) k = (ctx->mono_next + i) % vo_ctx::N_MONO_ALT;
     if (k < 0) return vo_fail(ctx, VO_E_STATE, "vo_mono_pair_begin: every asynchronous step is still open (end one first)");
     vo_ctx::MonoAlt& p = ctx->mono_alt[k];
-    if ((rc = mono_alt_prepare(ctx, k))) return rc;
+    for (int i = 0; i < vo_ctx::N_MONO_ALT; i++)            // (every alternate with the first step: see vo_pose_pair_begin)
+        if ((rc = mono_alt_prepare(ctx, (k + i) % vo_ctx::N_MONO_ALT))) return rc;
     FrameSlot& a = ctx->slots[slot_a];
     FrameSlot& b = ctx->slots[slot_b];
     memset(p.result, 0, MONO_HDR);
