@@ -44,17 +44,20 @@ SGBM = ("k_sgbm", "k_lr_", "k_ccl")
 f, _ = load("fetch")
 w, _ = load("write")
 kernels = sorted({k for (_, k) in list(f) + list(w)})
-npairs = max(len(v) for (c, k), v in f.items() if k.startswith("k_sgbm_planes"))
+# launches of the kernel every pair (C2 / C4) or frame (C5: monocular, no SGBM) runs exactly once
+_once = [len(v) for (c, k), v in f.items() if k.startswith("k_sgbm_planes")] or [len(v) for (c, k), v in f.items() if k.startswith("k_orb_pyramid")]
+npairs = max(_once)
+mono = not any(k.startswith("k_sgbm_planes") for (_, k) in f)
 rows, tot_f, tot_w, dom = [], 0.0, 0.0, None
 for k in kernels:
     fv, wv = f.get(("FETCH_SIZE", k), []), w.get(("WRITE_SIZE", k), [])
     mf, mw = (sum(fv) / len(fv) if fv else 0.0), (sum(wv) / len(wv) if wv else 0.0)
     if mf + mw >= 64:
         rows.append((k, max(len(fv), len(wv)), mf, mw))
-    if k.startswith(SGBM):
+    if k.startswith(SGBM) or (mono and k.startswith("k_")):      # (config 5: every kernel of the pipeline)
         tot_f += sum(fv) / npairs
         tot_w += sum(wv) / npairs
-    if k.startswith("k_sgbm_diag") and ", false, true>" in k and (dom is None or max(len(fv), len(wv)) > dom[2]):
+    if ((k.startswith("k_sgbm_diag") and ", false, true>" in k) or (mono and k.startswith("k_bf_knn2"))) and (dom is None or max(len(fv), len(wv)) > dom[2]):
         dom = (k, int((2 * mf + mw) * 1024), max(len(fv), len(wv)))    # (the strip width most of the pairs ran with)
 rows.sort(key=lambda r: -(r[2] * 2 + r[3]))
 with open(os.path.join(dst, "%s_pmc_%s_summary.csv" % (tag, low)), "w") as fh:
@@ -66,7 +69,7 @@ o, meta = load("occ")
 valu_per_pair = None
 if o:
     # vector instructions of ALL kernels of a pair (SQ_INSTS_VALU counts wave-instructions), from the occupancy pass
-    n_occ = max(len(v) for (c, k), v in o.items() if c == "SQ_INSTS_VALU" and k.startswith(("k_sgbm_planes", "k_orb_pyramid")))
+    n_occ = max(len(v) for (c, k), v in o.items() if c == "SQ_INSTS_VALU" and k.startswith("k_orb_pyramid" if mono else ("k_sgbm_planes", "k_orb_pyramid")))
     valu_per_pair = int(sum(sum(v) for (c, k), v in o.items() if c == "SQ_INSTS_VALU" and k.startswith("k_")) / n_occ)
 json.dump({"workload": wl, "csrc_digest": digest, "tag": tag,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 6 --warmup 2 --cpu-pairs 0 --no-post` "
@@ -85,7 +88,7 @@ if o:
         fh.write("kernel,dispatches,grid_threads,workgroup,vgprs,lds_bytes,waves,waves_per_simd_if_all_resident,valu_busy_frac_of_wave_cycles,"
                  "active_any_frac,wait_any_frac(parked: s_waitcnt/barrier),wait_inst_any_frac(issue stall),wave_cycles_per_wave,valu_insts_per_wave,gui_active_cycles\n")
         for k in sorted(meta):
-            if not k.startswith(("k_sgbm", "k_orb", "k_pose", "k_bf", "k_lr", "k_ccl")):
+            if not k.startswith(("k_sgbm", "k_orb", "k_pose", "k_bf", "k_lr", "k_ccl", "k_ransac", "k_ratio")):
                 continue
             g = lambda c: (sum(o.get((c, k), [0.0])) / max(len(o.get((c, k), [0.0])), 1))
             waves, wc = g("SQ_WAVES"), g("SQ_WAVE_CYCLES")
