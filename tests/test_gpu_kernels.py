@@ -127,6 +127,37 @@ def test_bf_knn2_tile_and_slice_edges_and_adversarial_bit_patterns(oracle):
     ctx.close()
 
 
+def test_bf_knn2_slice_hand_off_under_uneven_load(oracle):
+    """The slices of a train set are merged inside the launch: write-through stores, the storing wave's wait, one agent-scope
+    ticket, write-through-aware loads by the wave whose ticket came last -- no fence.  A hand-off like that has to be tested
+    under UNEVEN load with every word checked (MI355X_MICROARCH.md): 60 launches of changing size, each result compared with
+    the oracle's in full, while look-ahead engines run disparity + ORB of staged pairs beside them on the same GPU (other
+    workgroups occupy CUs and L2s, the matcher's workgroups start at different times and on different XCDs), the scratch
+    behind the distances being reused by every launch."""
+    from openvo_amd import StereoCamera, StereoOdometer
+    from openvo_amd.synth import Corridor
+    c = Corridor("C1")
+    cam = StereoCamera(c.K(), c.dist(), c.K(), c.dist(), c.rect_params(), c.sgbm_params(), (c.w, c.h), max_keypoints=2000)
+    odo = StereoOdometer(cam, nfeatures=500, preprocessed_frames=True)
+    staged = cam.stage_pairs(c.pairs(0, 24))
+    ctx = cam._ctx
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (4000, 32), dtype=np.uint8)
+    k = 0
+    for rep in range(60):
+        if rep % 3 == 0:                                     # (keeps the engines busy: the next pairs' disparity + keypoints start here)
+            odo.update(staged[k % 24], None)
+            k += 1
+        nq, nt = int(rng.integers(65, 2000)), int(rng.integers(40, 4000))
+        q = base[rng.integers(0, 4000, nq)] ^ (rng.integers(0, 256, (nq, 32), dtype=np.uint8) & rng.integers(0, 256, (nq, 32), dtype=np.uint8) & 0x11)
+        t = base[rng.permutation(4000)[:nt]]                  # near-duplicates of the queries: small distances, many close calls
+        gi, gd = ctx.bf_knn2(q, t)
+        ri, rd = oracle.bf_knn2_hamming(q, t)
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd), (rep, nq, nt)
+    assert ctx.sgbm_sweep_status() == 0
+    ctx.close()
+
+
 @pytest.mark.parametrize("nq,nt", [(500, 500), (1, 2), (7, 1), (3, 0), (1000, 777)])
 def test_bf_knn2_bit_exact(oracle, ctx_small, nq, nt):
     rng = np.random.default_rng(nq * 1000 + nt)
