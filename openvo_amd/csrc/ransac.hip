@@ -326,8 +326,59 @@ __global__ void k_ransac_pick(const double* __restrict__ E_all, const int32_t* _
 // host synchronisation at the end) or those of an asynchronous alternate (vo_mono_pair_begin / _end).
 struct MonoDev { int32_t* d_best; double* d_E9; uint8_t* d_mask; };
 
+// The end of an asynchronous pair step as ONE launch (was three kernels and seven copy commands: at 8000 keypoints the
+// monocular loop is bound by the host thread's queue entries): argmax of the hypotheses' inlier counts (most inliers, then the
+// lowest index) -> the winner's E -> its inlier mask over the M correspondences -> the whole record -- M, winner, count, E,
+// mask, the surviving index pairs and the second frame's keypoint positions -- written straight into the alternate's PINNED
+// host record (one block: the record is 140 KB at 8000 keypoints).  Element for element the arithmetic of k_ransac_best /
+// k_ransac_mask / k_ransac_pick.
+__global__ void __launch_bounds__(1024) k_mono_finish(const int32_t* __restrict__ counts, int iters, const double* __restrict__ E_all,
+                                                      const float* __restrict__ F_all, const float* __restrict__ p1, const float* __restrict__ p2,
+                                                      int nq, const int* __restrict__ n_dev, int min_n, float thr2, const int32_t* __restrict__ mq,
+                                                      const int32_t* __restrict__ mt, const float* __restrict__ xy_b, int nb, int want, size_t cap,
+                                                      uint8_t* __restrict__ rec, size_t hdr)
+{
+    __shared__ long long s_key[16];
+    __shared__ int s_best[2];
+    long long key = -1;
+    for (int h = threadIdx.x; h < iters; h += blockDim.x) {
+        const long long k = ((long long)counts[h] << 32) | (long long)(0x7fffffff - h);   // most inliers, then lowest index
+        key = k > key ? k : key;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const long long other = __shfl_xor(key, o, 64); key = other > key ? other : key; }
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < (int)(blockDim.x >> 6); q++) key = s_key[q] > key ? s_key[q] : key;
+        s_best[0] = 0x7fffffff - (int)(key & 0x7fffffffLL);
+        s_best[1] = (int)(key >> 32);
+    }
+    __syncthreads();
+    const int best = s_best[0], m = *n_dev;
+    int32_t* const h32 = (int32_t*)rec;
+    if (threadIdx.x == 0) { h32[0] = m; h32[1] = best; h32[2] = s_best[1]; }
+    if (threadIdx.x < 9) ((double*)(rec + 64))[threadIdx.x] = E_all[(size_t)best * 9 + threadIdx.x];
+    if (!want) return;
+    uint8_t* const q = rec + hdr;
+    float Fl[9];
+    for (int k = 0; k < 9; k++) Fl[k] = F_all[(size_t)best * 9 + k];
+    const int live = m < min_n ? 0 : m;
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+        uint8_t in = 0;
+        if (i < live) {
+            const float2 a = ((const float2*)p1)[i], b = ((const float2*)p2)[i];
+            in = sampson_inlier(Fl, a.x, a.y, b.x, b.y, thr2) ? 1 : 0;
+        }
+        q[i] = in;
+        ((int32_t*)(q + cap))[i] = mq[i];
+        ((int32_t*)(q + cap * 5))[i] = mt[i];
+    }
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) ((float2*)(q + cap * 9))[i] = ((const float2*)xy_b)[i];
+}
+
+struct MonoTail { const int32_t* counts; const double* E; const float* F; float thr2; int min_n; };
 static int mono_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, const double* K4v, int iters, float thr, uint32_t seed,
-                        int solver, MonoDev& o)
+                        int solver, MonoDev& o, MonoTail* tail = nullptr)
 {
     const int min_n = solver == 5 ? 6 : 8;
     const int nq = a.n_kp;
@@ -366,9 +417,13 @@ static int mono_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, c
         else
             hipLaunchKernelGGL(k_ransac_hyp, dim3(div_up(iters, 64)), dim3(64), 0, ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, K, iters, seed, d_E, d_F, ctx->mw->m_count);
         hipLaunchKernelGGL(k_ransac_score, dim3(div_up(iters, 4)), dim3(256), 0, ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, d_F, iters, thr2, d_counts, ctx->mw->m_count, min_n);
-        hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(1024), 0, ctx->stream, d_counts, iters, o.d_best);
-        hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, d_F, o.d_best, thr2, o.d_mask, ctx->mw->m_count, min_n);
-        hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, ctx->stream, d_E, o.d_best, o.d_E9);
+        if (tail) {                                  // the asynchronous step ends with k_mono_finish (one launch, record written in place)
+            tail->counts = d_counts; tail->E = d_E; tail->F = d_F; tail->thr2 = thr2; tail->min_n = min_n;
+        } else {
+            hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(1024), 0, ctx->stream, d_counts, iters, o.d_best);
+            hipLaunchKernelGGL(k_ransac_mask, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, ctx->mw->xy_a, ctx->mw->xy_b, nq, d_F, o.d_best, thr2, o.d_mask, ctx->mw->m_count, min_n);
+            hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, ctx->stream, d_E, o.d_best, o.d_E9);
+        }
         VO_CHECK_LAUNCH(ctx);
     }
     return VO_OK;
@@ -509,21 +564,15 @@ extern "C" int vo_mono_pair_begin(vo_ctx* ctx, int slot_a, int slot_b, double ra
         rc = e == hipSuccess ? VO_OK : vo_fail(ctx, VO_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
         if (!rc && a.n_kp > 0) {
             MonoDev o;
-            rc = mono_enqueue(ctx, a, b, ratio, K4v, iters, thr, seed, solver, o);
-            uint8_t* r = p.result;
-            const size_t nq = (size_t)a.n_kp, nb = (size_t)b.n_kp;
-            if (!rc) e = hipMemcpyAsync(r, ctx->mw->m_count, 4, hipMemcpyDeviceToHost, ctx->stream);
-            if (!rc && e == hipSuccess) e = hipMemcpyAsync(r + 4, o.d_best, 8, hipMemcpyDeviceToHost, ctx->stream);
-            if (!rc && e == hipSuccess) e = hipMemcpyAsync(r + 64, o.d_E9, 72, hipMemcpyDeviceToHost, ctx->stream);
-            if (!rc && p.want) {
-                uint8_t* q = r + MONO_HDR;
-                const size_t cap = (size_t)ctx->kp_cap;
-                if (e == hipSuccess) e = hipMemcpyAsync(q, o.d_mask, nq, hipMemcpyDeviceToHost, ctx->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(q + cap, ctx->mw->mq_idx, nq * 4, hipMemcpyDeviceToHost, ctx->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(q + cap * 5, ctx->mw->mt_idx, nq * 4, hipMemcpyDeviceToHost, ctx->stream);
-                if (e == hipSuccess && nb) e = hipMemcpyAsync(q + cap * 9, b.kp_xy, nb * 8, hipMemcpyDeviceToHost, ctx->stream);
+            MonoTail tl;
+            rc = mono_enqueue(ctx, a, b, ratio, K4v, iters, thr, seed, solver, o, &tl);
+            if (!rc) {
+                // (p.result is pinned host memory: the kernel writes the record across the link itself -- no copy command)
+                hipLaunchKernelGGL(k_mono_finish, dim3(1), dim3(1024), 0, ctx->stream, tl.counts, iters, tl.E, tl.F, ctx->mw->xy_a, ctx->mw->xy_b, a.n_kp,
+                                   ctx->mw->m_count, tl.min_n, tl.thr2, ctx->mw->mq_idx, ctx->mw->mt_idx, b.kp_xy, b.n_kp, p.want ? 1 : 0, (size_t)ctx->kp_cap,
+                                   p.result, MONO_HDR);
+                if (hipGetLastError() != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "k_mono_finish: launch failed");
             }
-            if (!rc && e != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
         }
         if (!rc && hipEventRecord(p.done, ctx->stream) != hipSuccess) rc = vo_fail(ctx, VO_E_HIP, "hipEventRecord failed");
     }
