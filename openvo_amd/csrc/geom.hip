@@ -1236,7 +1236,8 @@ __global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* _
                                                      float* __restrict__ qb, int lds_m_cap, size_t lds_bits_cap,
                                                      const int* __restrict__ flags_dev, double outlier_thr, int min_matches,
                                                      double* __restrict__ errs, float* __restrict__ ra, float* __restrict__ rb,
-                                                     PoseOut* __restrict__ out, const uint8_t* __restrict__ lanebytes, int* __restrict__ g_sets)
+                                                     PoseOut* __restrict__ out, const uint8_t* __restrict__ lanebytes, int* __restrict__ g_sets,
+                                                     unsigned long long* __restrict__ host_rec)
 {
     extern __shared__ __attribute__((aligned(16))) int s_mem[];
     STAMP(0);
@@ -1258,6 +1259,12 @@ __global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* _
     __syncthreads();
     pose_fit_block(qa, qb, outlier_thr, min_matches, errs, ra, rb, out);
     STAMP(9);
+    // the finished record goes straight into the caller's PINNED host record (the copy command that used to follow this kernel
+    // was one more entry on the pose stream's queue: 0.1 - 0.2 ms of latency beside 16 busy engines).  The record's fields were
+    // written by several threads of this block: the stores are complete behind the barrier, the loads bypass this CU's L1.
+    __syncthreads();
+    if (host_rec && threadIdx.x < sizeof(PoseOut) / 8)
+        host_rec[threadIdx.x] = __hip_atomic_load((const unsigned long long*)out + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // enqueue the whole fused step for two slots on ctx->stream with the scratch currently installed in ctx; the
@@ -1267,7 +1274,8 @@ size_t pose_ws_bytes(int nq)
     return (size_t)nq * words * 8 + (size_t)nq * 4 + (size_t)nq * 12 * 4 + (size_t)nq * 8 + (size_t)nq * 64 + ((size_t)nq + 2) * 16 + 4096;
 }
 
-// PoseOut record is copied to host_out (pinned) at the end.  No host synchronisation.
+// k_pose_solve writes the finished PoseOut record into host_out (pinned host memory the device can address) itself.  No host
+// synchronisation, no copy command.
 static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, int min_matches, double rigidity_thr,
                         double outlier_thr, void* host_out)
 {
@@ -1322,9 +1330,8 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
         const bool sets_global = (size_t)m_cap * 16 > 56 * 1024;      // > 3584 keypoints: the sets move to the workspace, LDS stays empty
         hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(1024), sets_global ? 0 : (size_t)m_cap * 16 + bits_cap, ctx->stream, d_bits, words, d_ncons, d_m,
                            use_filter, ctx->mw->pts_a, ctx->mw->pts_b, d_qa, d_qb, m_cap, bits_cap, d_flags, outlier_thr, min_matches, d_errs,
-                           d_ra, d_rb, d_out, d_lanebytes, sets_global ? d_sets : nullptr);
+                           d_ra, d_rb, d_out, d_lanebytes, sets_global ? d_sets : nullptr, (unsigned long long*)host_out);
         VO_CHECK_LAUNCH(ctx);
-        VO_HIP(ctx, hipMemcpyAsync(host_out, d_out, sizeof(PoseOut), hipMemcpyDeviceToHost, ctx->stream));
     }
     return VO_OK;
 }
