@@ -1237,13 +1237,40 @@ __global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* _
                                                      const int* __restrict__ flags_dev, double outlier_thr, int min_matches,
                                                      double* __restrict__ errs, float* __restrict__ ra, float* __restrict__ rb,
                                                      PoseOut* __restrict__ out, const uint8_t* __restrict__ lanebytes, int* __restrict__ g_sets,
-                                                     unsigned long long* __restrict__ host_rec)
+                                                     unsigned long long* __restrict__ host_rec, int cons_inline, float cons_thr)
 {
     extern __shared__ __attribute__((aligned(16))) int s_mem[];
     STAMP(0);
     const int m = *m_dev;
     const bool fast = use_filter && m > 0 && m <= 512 && lds_bits_cap >= (size_t)m * 64;
-    if (fast) {
+    if (fast && cons_inline) {
+        // up to 512 matches the consistency rows are computed HERE, straight into the LDS bytes the greedy loop reads (row i by
+        // wave i mod 16: the arithmetic of k_pose_cons_bits, value for value) -- one launch and one global round trip less on
+        // the pose stream; the row counts go into the `nc` quarter of the set arrays, which the register-resident loop leaves free
+        uint8_t* const lb = (uint8_t*)(s_mem + 4 * lds_m_cap);
+        int* const nc = s_mem + 3 * lds_m_cap;
+        const int lane = threadIdx.x & 63, words = (m + 63) >> 6;
+        for (int i = threadIdx.x >> 6; i < m; i += (int)(blockDim.x >> 6)) {
+            const float cix = pb[3 * i], ciy = pb[3 * i + 1], ciz = pb[3 * i + 2];
+            const float pix = pa[3 * i], piy = pa[3 * i + 1], piz = pa[3 * i + 2];
+            unsigned byte = 0;
+            int cnt = 0;
+            for (int k = 0; k < words; k++) {
+                const int j = 64 * k + lane;
+                bool c = false;
+                if (j < m) {
+                    float ax = cix - pb[3 * j], ay = ciy - pb[3 * j + 1], az = ciz - pb[3 * j + 2];
+                    float bx = pix - pa[3 * j], by = piy - pa[3 * j + 1], bz = piz - pa[3 * j + 2];
+                    float na = sqrtf((ax * ax + ay * ay) + az * az), nb = sqrtf((bx * bx + by * by) + bz * bz);
+                    c = fabsf(na - nb) < cons_thr;
+                }
+                cnt += __popcll(__ballot(c));
+                byte |= (unsigned)c << (k & 7);
+            }
+            lb[(size_t)i * 64 + lane] = (uint8_t)byte;
+            if (lane == 0) nc[i] = cnt;
+        }
+    } else if (fast) {
         // lanebits[row][lane] = bit k set when row is consistent with element lane + 64 k (written by k_pose_cons_bits):
         // into LDS, 16 bytes per thread
         uint4* dst = (uint4*)(s_mem + 4 * lds_m_cap);
@@ -1253,7 +1280,8 @@ __global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* _
     __syncthreads();
     // the four per-match int arrays of the greedy loop: LDS, or (more matches than 56 KB of LDS hold) the global workspace
     if (threadIdx.x < 64)
-        pose_clique_wave(g_sets ? g_sets : s_mem, bits, words_cap, ncons, m_dev, use_filter, pa, pb, qa, qb, &out->n1, lds_m_cap, lds_bits_cap, fast);
+        pose_clique_wave(g_sets ? g_sets : s_mem, bits, words_cap, (fast && cons_inline) ? s_mem + 3 * lds_m_cap : ncons, m_dev, use_filter, pa, pb, qa, qb,
+                         &out->n1, lds_m_cap, lds_bits_cap, fast);
     if (threadIdx.x == 0) out->flags |= *flags_dev;
     STAMP(1);
     __syncthreads();
@@ -1319,18 +1347,20 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
                            ctx->mw->mq_idx, ctx->mw->mt_idx, ctx->mw->xy_a, ctx->mw->xy_b, d_m, d_out, d_flags, ta, tb, x1 - x0, y1 - y0, ctx->mw->pts_a,
                            ctx->mw->pts_b, ctx->mw->st_a, ctx->mw->st_b, d_ncons);
         const int use_filter = rigidity_thr > 0;
-        if (use_filter)
-            hipLaunchKernelGGL(k_pose_cons_bits, dim3(nq), dim3(64), 0, ctx->stream, ctx->mw->pts_a, ctx->mw->pts_b, d_m, (float)rigidity_thr,
-                               d_bits, words, d_ncons, d_lanebytes);
         // LDS: 4 int arrays of nq (rounded to even so the bit matrix stays 8-byte aligned) + bit matrix if <= 48 KB
         const int m_cap = (nq + 1) & ~1;
         size_t bits_cap = (size_t)nq * words * 8;
         if (nq <= 512 && bits_cap < (size_t)nq * 64) bits_cap = (size_t)nq * 64;   // one byte per (row, lane): the register-resident greedy loop
         if ((size_t)m_cap * 16 + bits_cap > 56 * 1024) bits_cap = 0;
         const bool sets_global = (size_t)m_cap * 16 > 56 * 1024;      // > 3584 keypoints: the sets move to the workspace, LDS stays empty
+        // up to 512 query keypoints (M <= nq) k_pose_solve computes the consistency rows itself, into LDS: no launch of their own
+        const bool cons_inline = use_filter && nq <= 512 && !sets_global && bits_cap >= (size_t)nq * 64;
+        if (use_filter && !cons_inline)
+            hipLaunchKernelGGL(k_pose_cons_bits, dim3(nq), dim3(64), 0, ctx->stream, ctx->mw->pts_a, ctx->mw->pts_b, d_m, (float)rigidity_thr,
+                               d_bits, words, d_ncons, d_lanebytes);
         hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(1024), sets_global ? 0 : (size_t)m_cap * 16 + bits_cap, ctx->stream, d_bits, words, d_ncons, d_m,
                            use_filter, ctx->mw->pts_a, ctx->mw->pts_b, d_qa, d_qb, m_cap, bits_cap, d_flags, outlier_thr, min_matches, d_errs,
-                           d_ra, d_rb, d_out, d_lanebytes, sets_global ? d_sets : nullptr, (unsigned long long*)host_out);
+                           d_ra, d_rb, d_out, d_lanebytes, sets_global ? d_sets : nullptr, (unsigned long long*)host_out, cons_inline ? 1 : 0, (float)rigidity_thr);
         VO_CHECK_LAUNCH(ctx);
     }
     return VO_OK;
