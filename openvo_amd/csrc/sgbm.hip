@@ -747,6 +747,119 @@ __global__ void __launch_bounds__(256) k_sgbm_we(const int16_t* __restrict__ C, 
     }
 }
 
+// The same two passes with a row CUT IN TWO at its middle column m = W1 / 2 (round 5): two waves per group of four rows, each
+// owning a half, both running the same code with opposite signs.  "Forward" is the direction that leaves the middle (W for the
+// right half [m, W1), E for the left half [0, m)), "backward" the one that arrives there.  Phase 1: each wave runs its backward
+// direction from the image border to the middle, keeping every 8th column (checkpoints) -- and what it holds at the end is
+// exactly the state the OTHER half's forward direction starts from (L_W(m - 1) for the right half, L_E(m) for the left one): one
+// exchange through LDS behind the kernel's only barrier.  Phase 2: k_sgbm_we's second pass, outward from the middle.  The same
+// 3 path steps per cell and the same bytes; a wave's chain is 1.5 W1 dependent steps instead of 3 W1 and twice as many waves
+// share the work (360 at config 2).  Needs W1 % 16 == 0 (otherwise k_sgbm_we).
+template <int NP, bool PAD>
+__global__ void __launch_bounds__(256) k_sgbm_we2(const int16_t* __restrict__ C, int16_t* __restrict__ Swe, int16_t* __restrict__ ckpt,
+                                                 SgbmGeom g, int16_t* __restrict__ dump)
+{
+    __shared__ uint32_t s_x[4][NP][64];
+    const int lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15, wv = threadIdx.x >> 6;
+    const int group = blockIdx.x * 2 + (wv >> 1);          // four rows
+    const bool right = (wv & 1) != 0;                      // this wave's half
+    const int y = group * 4 + row;
+    const bool live = y < g.H;                             // (a group past the image still runs: the barrier below wants every wave)
+    const int yc = live ? y : g.H - 1;
+    const int W1 = g.W1, nh = W1 >> 1, nseg = nh >> 3, nseg_row = W1 >> 3;
+    const int d0 = l16 * 2 * NP;
+    unsigned padreg = 0;
+    if constexpr (PAD) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) padreg |= (unsigned)(d0 + 2 * k >= g.D) << k;
+    }
+    const uint32_t P1_2 = pk_rep(g.P1), P2_2 = pk_rep(g.P2);
+    const ptrdiff_t Dp = g.Dp;
+    const ptrdiff_t fs = right ? Dp : -Dp;                 // one column in the forward direction
+    const int x0 = right ? nh : nh - 1;                    // forward index f <-> column x0 + (right ? f : -f)
+    const int16_t* const cf = C + ((size_t)yc * W1 + x0) * Dp + d0;               // cost cells of forward index 0
+    int16_t* const sink = dump + lane * 2 * NP;
+    int16_t* const krow = live ? ckpt + ((size_t)yc * nseg_row + (right ? nseg : 0)) * Dp + d0 : sink;   // this half's checkpoints: L_back at f = 8 s
+    const ptrdiff_t kstep = live ? Dp : 0;
+    LV<NP> border;
+#pragma unroll
+    for (int k = 0; k < NP; k++) border.r[k] = ((padreg >> k) & 1u) ? MAXC2 : 0u;
+
+    // ---- phase 1: the backward direction, from the border (f = nh - 1) to the middle (f = 0), keeping every 8th column ----
+    LV<NP> Lp = border;
+    {
+        uint32_t delta2 = P2_2;
+        LV<NP> cbuf[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) cbuf[k] = lv_load<NP>(cf + (ptrdiff_t)(nh - 1 - k) * fs);
+        const int16_t* pld = cf + (ptrdiff_t)(nh - 9) * fs;        // (nh >= 16 is checked by the launcher)
+        for (int s = nseg - 1; s >= 0; s--) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const LV<NP> Cv = cbuf[k];
+                cbuf[k] = lv_load<NP>(pld);
+                pld -= (8 * s - k - 1 > 0) ? fs : 0;               // next forward index to fetch is 8 s - k - 1; stop at 0
+                const LV<NP> L = path_step2<NP, PAD>(Cv, Lp, delta2, P1_2, padreg);
+                delta2 = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(L))), P2_2);
+                Lp = L;
+                if (k == 7) lv_store<NP>(krow + (ptrdiff_t)s * kstep, L);   // forward index 8 s
+            }
+        }
+    }
+    // what this wave holds now (its backward direction at f = 0) is the other half's forward predecessor
+#pragma unroll
+    for (int k = 0; k < NP; k++) s_x[wv][k][lane] = Lp.r[k];
+    // (the checkpoints are read back by the lanes that wrote them: let the stores land before the first load is issued)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- phase 2: per segment the backward direction again (from the checkpoint on its far side), then forward, store the sum ----
+    {
+        LV<NP> LpF;
+#pragma unroll
+        for (int k = 0; k < NP; k++) LpF.r[k] = s_x[wv ^ 1][k][lane];
+        uint32_t dF = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(LpF))), P2_2);
+        LV<NP> cseg[8], cnext[8], ck, cknext;
+#pragma unroll
+        for (int k = 0; k < 8; k++) cseg[k] = lv_load<NP>(cf + (ptrdiff_t)k * fs);
+        ck = lv_load<NP>(krow + (ptrdiff_t)(nseg > 1 ? 1 : 0) * kstep);
+        int16_t* pst = live ? Swe + ((size_t)yc * W1 + x0) * Dp + d0 : sink;
+        const ptrdiff_t sstep = live ? fs : 0;
+        for (int s = 0; s < nseg; s++) {
+            const int sn = min(s + 1, nseg - 1);
+#pragma unroll
+            for (int k = 0; k < 8; k++) cnext[k] = lv_load<NP>(cf + (ptrdiff_t)(8 * sn + k) * fs);
+            cknext = lv_load<NP>(krow + (ptrdiff_t)min(sn + 1, nseg - 1) * kstep);
+            const bool last = s == nseg - 1;                          // the half's last segment starts the backward direction from the border
+            LV<NP> LpB;
+#pragma unroll
+            for (int q = 0; q < NP; q++) LpB.r[q] = last ? border.r[q] : ck.r[q];
+            uint32_t dB = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(ck))), P2_2);
+            dB = last ? P2_2 : dB;
+            LV<NP> Lb[8];
+#pragma unroll
+            for (int k = 7; k >= 0; k--) {
+                Lb[k] = path_step2<NP, PAD>(cseg[k], LpB, dB, P1_2, padreg);
+                dB = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(Lb[k]))), P2_2);
+                LpB = Lb[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const LV<NP> Lf = path_step2<NP, PAD>(cseg[k], LpF, dF, P1_2, padreg);
+                dF = pk_add(pk_rep((int)row_min_u32(lane_min16<NP>(Lf))), P2_2);
+                LpF = Lf;
+                LV<NP> S;
+#pragma unroll
+                for (int q = 0; q < NP; q++) S.r[q] = pk_add_sat(Lf.r[q], Lb[k].r[q]);
+                lv_store_nt<NP>(pst, S);
+                pst += sstep;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) cseg[k] = cnext[k];
+            ck = cknext;
+        }
+    }
+}
+
 // The same pairing for ANY two opposite directions (MODE_HH: W/E, NW/SE, NE/SW): a scan line of direction (sx, sy) is
 // also a scan line of (-sx, -sy) walked from its other end.  Pass 1 runs the backward direction from the line's far end
 // and keeps L at every 8th step (step index i = 8 j, stored AT the pixel it belongs to, in a scratch volume that is
@@ -1540,7 +1653,10 @@ static int launch_agg(vo_ctx* ctx, const SgbmGeom& g, const PathPlan& plan, size
             if (ctx->tune_diag_dbg & 8) {
             } else if (g.W1 % 8 == 0 && g.W1 >= 16) {
                 const int nw = div_up(g.H, 4);
-                if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->ws->C, Swe, ck, g, ctx->dump);
+                if (g.W1 % 16 == 0 && g.W1 >= 32) {               // a row cut at its middle: two waves per four rows, half the chain each
+                    if (pad) hipLaunchKernelGGL((k_sgbm_we2<NP, true>), dim3(div_up(nw, 2)), dim3(256), 0, ctx->stream, ctx->ws->C, Swe, ck, g, ctx->dump);
+                    else hipLaunchKernelGGL((k_sgbm_we2<NP, false>), dim3(div_up(nw, 2)), dim3(256), 0, ctx->stream, ctx->ws->C, Swe, ck, g, ctx->dump);
+                } else if (pad) hipLaunchKernelGGL((k_sgbm_we<NP, true>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->ws->C, Swe, ck, g, ctx->dump);
                 else hipLaunchKernelGGL((k_sgbm_we<NP, false>), dim3(div_up(nw, 4)), dim3(256), 0, ctx->stream, ctx->ws->C, Swe, ck, g, ctx->dump);
             } else {
                 PathPlan pp = plan;                                  // the W / E pair alone: one line per image row
