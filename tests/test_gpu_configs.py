@@ -162,6 +162,10 @@ SIZES = [  # name, mode, numDisparities, (w, h) crop or None, compute waves per 
     # 11 compute waves per strip: the width the look-ahead engines use by default (launch_diag)
     ("T0", 0, 48, None, 11, "diag"), ("C1", 0, 64, None, 11, "diag"), ("C1", 1, 64, None, 11, "diag"), ("C1", 1, 112, (632, 471), 11, "diag"),
     ("C1", 0, 32, None, 11, "diag"), ("C1", 0, 96, None, 11, "diag"), ("C1", 0, 64, (79, 64), 11, "ragged"), ("C1", 1, 112, (200, 59), 11, "diag"),
+    # W + E with every row cut at its middle (k_sgbm_we2: width - D a multiple of 16): the smallest halves (two and three
+    # segments), an odd number of four-row groups (the last workgroup's second group lies outside the image), a width - D that
+    # is a multiple of 8 only (k_sgbm_we, whole rows) beside them
+    ("C1", 0, 64, (96, 59), 7, "diag"), ("C1", 1, 64, (112, 41), 11, "diag"), ("C1", 0, 64, (104, 59), 7, "diag"), ("T0", 1, 32, (320, 237), 11, "diag"),
 ]
 
 
@@ -169,7 +173,7 @@ SIZES = [  # name, mode, numDisparities, (w, h) crop or None, compute waves per 
 def test_diagonal_schedule_sizes_and_modes(oracle, name, mode, ndisp, crop, waves, sched, monkeypatch):
     """The aggregation schedule (W + E as one volume, then NW / N / NE + WTA in the diagonal sweep; MODE_HH with the
     reverse sweep first) against the oracle across register counts, padded disparity ranges, strip widths, ragged widths
-    (k_sgbm_pair instead of k_sgbm_we) and images smaller than a strip."""
+    (k_sgbm_pair instead of k_sgbm_we / k_sgbm_we2) and images smaller than a strip."""
     c = Corridor(name)
     L, R = c.pair(4)
     if crop:
