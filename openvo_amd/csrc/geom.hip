@@ -1249,6 +1249,14 @@ __global__ void __launch_bounds__(1024) k_pose_solve(const unsigned long long* _
         // the pose stream; the row counts go into the `nc` quarter of the set arrays, which the register-resident loop leaves free
         uint8_t* const lb = (uint8_t*)(s_mem + 4 * lds_m_cap);
         int* const nc = s_mem + 3 * lds_m_cap;
+        // both point sets into LDS first (behind the row bytes): a row reads every point, and from global memory each of its
+        // steps waited for a round trip (29 us for 250 matches; 8 us from LDS)
+        float* const s_pa = (float*)((uint8_t*)(s_mem + 4 * lds_m_cap) + lds_bits_cap);
+        float* const s_pb = s_pa + 3 * lds_m_cap;
+        for (int k = threadIdx.x; k < 3 * m; k += blockDim.x) { s_pa[k] = pa[k]; s_pb[k] = pb[k]; }
+        __syncthreads();
+        const float* const pa = s_pa;                     // (shadow the global pointers for the rows below)
+        const float* const pb = s_pb;
         const int lane = threadIdx.x & 63, words = (m + 63) >> 6;
         for (int i = threadIdx.x >> 6; i < m; i += (int)(blockDim.x >> 6)) {
             const float cix = pb[3 * i], ciy = pb[3 * i + 1], ciz = pb[3 * i + 2];
@@ -1354,11 +1362,13 @@ static int pose_enqueue(vo_ctx* ctx, FrameSlot& a, FrameSlot& b, double ratio, i
         if ((size_t)m_cap * 16 + bits_cap > 56 * 1024) bits_cap = 0;
         const bool sets_global = (size_t)m_cap * 16 > 56 * 1024;      // > 3584 keypoints: the sets move to the workspace, LDS stays empty
         // up to 512 query keypoints (M <= nq) k_pose_solve computes the consistency rows itself, into LDS: no launch of their own
-        const bool cons_inline = use_filter && nq <= 512 && !sets_global && bits_cap >= (size_t)nq * 64;
+        // (needs both point sets in LDS beside the sets and the row bytes: 24 bytes per match more)
+        const bool cons_inline = use_filter && nq <= 512 && !sets_global && bits_cap >= (size_t)nq * 64 &&
+                                 (size_t)m_cap * 16 + bits_cap + (size_t)m_cap * 24 <= 60 * 1024;
         if (use_filter && !cons_inline)
             hipLaunchKernelGGL(k_pose_cons_bits, dim3(nq), dim3(64), 0, ctx->stream, ctx->mw->pts_a, ctx->mw->pts_b, d_m, (float)rigidity_thr,
                                d_bits, words, d_ncons, d_lanebytes);
-        hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(1024), sets_global ? 0 : (size_t)m_cap * 16 + bits_cap, ctx->stream, d_bits, words, d_ncons, d_m,
+        hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(1024), sets_global ? 0 : (size_t)m_cap * 16 + bits_cap + (cons_inline ? (size_t)m_cap * 24 : 0), ctx->stream, d_bits, words, d_ncons, d_m,
                            use_filter, ctx->mw->pts_a, ctx->mw->pts_b, d_qa, d_qb, m_cap, bits_cap, d_flags, outlier_thr, min_matches, d_errs,
                            d_ra, d_rb, d_out, d_lanebytes, sets_global ? d_sets : nullptr, (unsigned long long*)host_out, cons_inline ? 1 : 0, (float)rigidity_thr);
         VO_CHECK_LAUNCH(ctx);

@@ -1711,16 +1711,18 @@ static int sgbm_run_impl(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t*
 static uint32_t pk_rep_host(int v) { return (uint32_t)(v & 0xFFFF) * 0x00010001u; }
 static int post_rows_per_block(int w) { return std::min(6, (int)(150 * 1024 / ((size_t)w * 6)) - 2); }
 
-// The SGBM workspaces (planes, C, S volumes, CCL arrays) are shared by the main and the look-ahead
-// stream: a run on one stream must not start before the previous run -- possibly on the other
-// stream -- has finished.  An event chain orders them on the device without blocking the host.
+// The MAIN SGBM workspace (planes, C, S volumes, CCL arrays) is shared by the main stream and look-ahead engine 0's: a run on
+// one of them must not start before the previous run -- possibly on the other -- has finished.  An event chain orders them on
+// the device without blocking the host.  An engine's own workspace is only ever used on that engine's stream, which is ordered
+// already: no wait, no record (two packets less per pair on the engine's queue).
 int sgbm_run(vo_ctx* ctx, FrameSlot& f, int w, int h, const uint8_t* srcL, const uint8_t* srcR)
 {
-    if (ctx->ws->done_valid) VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ws->done, 0));
+    const bool shared = ctx->ws == &ctx->main_ws;
+    if (shared && ctx->ws->done_valid) VO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ws->done, 0));
     if (++ctx->sweep_gen_next <= 0) ctx->sweep_gen_next = 1;     // this run's generation: never 0 (FrameSlot::sweep_word)
     f.disp_gen = ctx->sweep_gen_next;
     int rc = sgbm_run_impl(ctx, f, w, h, srcL, srcR);
-    if (ctx->ws->done) {
+    if (shared && ctx->ws->done) {
         VO_HIP(ctx, hipEventRecord(ctx->ws->done, ctx->stream));
         ctx->ws->done_valid = true;
     }
