@@ -286,6 +286,10 @@ int vo_sgbm_last_schedule(vo_ctx* ctx, int* schedule_out);
  * whole one) between two of the context's volumes, timed with HIP events; *gb_per_s counts bytes read + bytes written.
  * Overwrites the cost volume: call it between, not inside, vo_sgbm_compute / vo_prefetch_pair sequences. */
 int vo_measure_copy(vo_ctx* ctx, int64_t bytes, int reps, int nontemporal, double* gb_per_s);
+/* Measurement aid: `reps` launches of the Hamming kNN-2 kernel (slot_a's descriptors against slot_b's) back to back on the main
+ * stream between two HIP events -> microseconds per launch (the event pair's own cost is spread over the launches).  The result
+ * arrays are the context's match scratch; nothing the caller holds changes.  Semantics of the kernel: stereo_odometer.py:163. */
+int vo_measure_knn(vo_ctx* ctx, int slot_a, int slot_b, int reps, double* us_per_launch);
 /* the shader clock the GPU holds right now (MHz): one wave counts its cycles (s_memtime) against the 100 MHz wall counter
  * (s_memrealtime) for `micros` microseconds on the context's main stream; synchronous.  Measurement aid (bench.py records it
  * after every timed window: a GPU that has been idle ramps its clock up over the first tens of milliseconds of work). */

@@ -31,7 +31,7 @@ SYMBOLS = [
     "vo_orb_detect_and_compute", "vo_orb_detect_and_compute_host", "vo_slot_num_keypoints", "vo_download_keypoints",
     "vo_bf_knn2_hamming", "vo_ratio_filter", "vo_points3d_at", "vo_bilinear_at", "vo_point_clouds",
     "vo_pose_pair", "vo_pose_pair_begin", "vo_pose_pair_end", "vo_ransac_essential", "vo_ransac_essential5", "vo_ransac_pnp", "vo_umeyama", "vo_rigid_clique", "vo_rodrigues", "vo_enable_timing", "vo_get_timings",
-    "vo_sgbm_last_geometry", "vo_host_stage_pair", "vo_host_stage_fetch", "vo_prefetch_host_staged", "vo_lookahead_depth", "vo_lookahead_drop", "vo_sgbm_last_schedule", "vo_measure_copy", "vo_shader_clock", "vo_sgbm_sweep_status", "vo_sgbm_sweep_stats",
+    "vo_sgbm_last_geometry", "vo_host_stage_pair", "vo_host_stage_fetch", "vo_prefetch_host_staged", "vo_lookahead_depth", "vo_lookahead_drop", "vo_sgbm_last_schedule", "vo_measure_copy", "vo_measure_knn", "vo_shader_clock", "vo_sgbm_sweep_status", "vo_sgbm_sweep_stats",
     "vo_upload_mono", "vo_prefetch_staged_mono", "vo_mono_pair", "vo_mono_pair_begin", "vo_mono_pair_end", "vo_slot_ready", "vo_host_stage_begin", "vo_host_stage_wait",
     "vo_device_count", "vo_mgpu_unique_id", "vo_mgpu_create", "vo_mgpu_destroy", "vo_mgpu_info", "vo_mgpu_last_error",
     "vo_mgpu_gather_poses", "vo_mgpu_all_gather_f64", "vo_mgpu_all_reduce_max_f64",
@@ -175,6 +175,7 @@ def lib():
         L.vo_sgbm_sweep_stats.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int]
         L.vo_measure_copy.argtypes = [vp, ctypes.c_int64, ci, ci, vp]
         L.vo_shader_clock.argtypes = [vp, ci, vp]
+        L.vo_measure_knn.argtypes = [vp, ci, ci, ci, vp]
         L.vo_upload_mono.argtypes = [vp, ci, vp, ci, ci, ci]
         L.vo_prefetch_staged_mono.argtypes = [vp, ci, ci, ci]
         L.vo_mono_pair.argtypes = [vp, ci, ci, cd, vp, ci, ctypes.c_float, ctypes.c_uint32, ci, vp, vp, vp, vp, vp, ci]
@@ -689,6 +690,12 @@ class Context:
         """GB/s (read + written) of a streaming device copy between two of the context's volumes."""
         g = ctypes.c_double(0.0)
         self._ck(self._lib.vo_measure_copy(self._h, int(nbytes), int(reps), 1 if nontemporal else 0, ctypes.byref(g)))
+        return g.value
+
+    def measure_knn(self, slot_a, slot_b, reps=20):
+        """microseconds per launch of the Hamming kNN-2 kernel on two slots' descriptors (`reps` launches between two events)."""
+        g = ctypes.c_double(0.0)
+        self._ck(self._lib.vo_measure_knn(self._h, int(slot_a), int(slot_b), int(reps), ctypes.byref(g)))
         return g.value
 
     def shader_clock(self, micros=200):

@@ -241,6 +241,31 @@ int match_knn2(vo_ctx* ctx, const uint8_t* dq, int nq, const uint8_t* dt, int nt
     return VO_OK;
 }
 
+extern "C" int vo_measure_knn(vo_ctx* ctx, int slot_a, int slot_b, int reps, double* us_per_launch)
+{
+    if (!ctx || !us_per_launch || reps <= 0 || reps > 10000 || slot_a < 0 || slot_a >= VO_NUM_SLOTS || slot_b < 0 || slot_b >= VO_NUM_SLOTS)
+        return vo_fail(ctx, VO_E_ARG, "vo_measure_knn: bad argument");
+    FrameSlot& a = ctx->slots[slot_a];
+    FrameSlot& b = ctx->slots[slot_b];
+    if (!a.has_kp || !b.has_kp || a.n_kp <= 0) return vo_fail(ctx, VO_E_STATE, "vo_measure_knn: both slots need keypoints");
+    VO_HIP(ctx, hipSetDevice(ctx->device));
+    { int rcw = slot_wait(ctx, a); if (!rcw) rcw = slot_wait(ctx, b); if (rcw) return rcw; }
+    hipEvent_t e0, e1;
+    VO_HIP(ctx, hipEventCreate(&e0));
+    VO_HIP(ctx, hipEventCreate(&e1));
+    int rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->mw->m_idx, ctx->mw->m_dist);      // warm-up (LDS attribute, caches)
+    if (!rc && hipEventRecord(e0, ctx->stream) != hipSuccess) rc = VO_E_HIP;
+    for (int r = 0; r < reps && !rc; r++) rc = match_knn2(ctx, a.desc, a.n_kp, b.desc, b.n_kp, ctx->mw->m_idx, ctx->mw->m_dist);
+    if (!rc && hipEventRecord(e1, ctx->stream) != hipSuccess) rc = VO_E_HIP;
+    float ms = 0.f;
+    if (!rc && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)) rc = VO_E_HIP;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc == VO_E_HIP ? vo_fail(ctx, VO_E_HIP, "vo_measure_knn: HIP error") : rc;
+    *us_per_launch = 1e3 * (double)ms / reps;
+    return VO_OK;
+}
+
 extern "C" int vo_bf_knn2_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx,
                                   int32_t* dist)
 {
