@@ -23,11 +23,12 @@ from openvo_amd.synth import Corridor               # noqa: E402
 class _Ctx:
     def synchronize(self): pass
     def enable_timing(self, on=True, stages=None): pass
-    def timings(self, reset=False): return {k: (0.0, 0) for k in ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose")}
+    def timings(self, reset=False): return {k: (0.0, 0) for k in ("upload", "sgbm_cost", "sgbm_agg", "sgbm_wta", "sgbm_post", "orb", "match", "pose", "knn")}
     def sgbm_sweep_status(self): return 0
     def sgbm_last_schedule(self): return 1
     def sgbm_last_geometry(self): return (1152 * 720 * 128, 3)
     def measure_copy(self, *a): return 1.0
+    def shader_clock(self, *a): return 2400.0
     def close(self): pass
 
 

@@ -409,6 +409,7 @@ def test_bench_orchestration_with_eight_socket_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["unit"] == "frame-pairs/s"
     assert len(d["window_values"]) == 2 and d["ms_per_step"] == pytest.approx(float(np.median(d["window_ms"])) / 4, rel=1e-3)
+    assert d["window_clock_mhz"] == [2400.0, 2400.0]                      # rank 0's clock reading after each window
     assert d["value"] == pytest.approx(4 * world / (d["ms_per_step"] * 4 / 1e3), rel=1e-3)      # whole-job pairs over the max-over-ranks time
     assert d["frames"] == world * 8 and d["accepted_frames"] == world * 8 and d["shard_boundaries_inexact"] == []
     assert d["cores_per_rank"] == pytest.approx(len(os.sched_getaffinity(0)) / world, abs=0.01)
